@@ -1,0 +1,188 @@
+"""CPU tests: the oracle (oracle/kd_oracle.py) reproduces the golden vectors that
+oracle/make_golden.py captured from the real reference.  No GPU, no reference needed."""
+import numpy as np
+import pytest
+import torch
+
+import kd_oracle as O
+from _util import digest, digest_close, golden, state_template
+
+FUSIONS = ("concat", "minimal", "weighted")
+B, HW, N, G = 2, 64, 512, 16
+TOL = 2e-5
+
+
+def _state(fusion, seed, grad=False):
+    return O.clone_state(O.randomize_state(state_template(fusion), seed), requires_grad=grad)
+
+
+def test_param_counts_pin():
+    pins = golden("pins.npz")
+    # fusion_ablation_results.json:4,9,14 (reference-published)
+    assert int(pins["concat_total"]) == 573442
+    assert int(pins["minimal_total"]) == 494978
+    assert int(pins["weighted_total"]) == 528132
+    assert int(pins["cam_params"]) == 363520
+    for f in FUSIONS:
+        st = state_template(f)
+        n = sum(st[k].numel() for k in O.trainable_keys(st))
+        assert n == int(pins[f"{f}_total"])
+
+
+@pytest.mark.parametrize("fusion", FUSIONS)
+@pytest.mark.parametrize("seed", (0, 1))
+def test_eval_forward(fusion, seed):
+    gd = golden(f"model_{fusion}_s{seed}.npz")
+    st = _state(fusion, seed)
+    images, pts, _ = O.make_inputs(B, HW, N, G, seed, pad_tail=40)
+    with torch.no_grad():
+        logits, mids = O.complete_model(images, pts, st, fusion_type=fusion, grid=(G, G))
+    np.testing.assert_allclose(logits.numpy(), gd["eval_logits"], atol=TOL, rtol=0)
+    margin = float(gd["eval_margin"])
+    if margin > 10 * TOL:
+        assert np.array_equal(logits.argmax(1).numpy(), gd["eval_argmax"])
+    if seed == 0:
+        for k in ("camera_feat", "lidar_feat", "pre_fusion", "post_fusion"):
+            np.testing.assert_allclose(mids[k].numpy(), gd["eval_" + k], atol=TOL, rtol=0)
+        ms = O.twinlite_encoder(images, st, "camera_encoder.", False, True)
+        for k, v in ms.items():
+            np.testing.assert_allclose(v.numpy(), gd["eval_" + k], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("fusion", FUSIONS)
+@pytest.mark.parametrize("seed", (0, 1))
+def test_train_ce_backward_and_adamw(fusion, seed):
+    gd = golden(f"model_{fusion}_s{seed}.npz")
+    st = _state(fusion, seed, grad=True)
+    images, pts, labels = O.make_inputs(B, HW, N, G, seed, pad_tail=40)
+    logits, mids = O.complete_model(images, pts, st, fusion_type=fusion, grid=(G, G), training=True)
+    loss = O.weighted_ce(logits, labels, torch.tensor([0.4, 3.5]))
+    assert abs(loss.item() - float(gd["train_loss"])) < 1e-5
+    np.testing.assert_allclose(logits.detach().numpy(), gd["train_logits"], atol=TOL, rtol=0)
+    loss.backward()
+    keys = [str(k) for k in gd["grad_keys"]]
+    assert keys == O.trainable_keys(st)
+    for k, want in zip(keys, gd["grad_digest"]):
+        assert digest_close(digest(st[k].grad), want), k
+    np.testing.assert_allclose(st["head.cls.weight"].grad.numpy(), gd["grad_head_cls_w"], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(st["camera_encoder.stem.0.weight"].grad.numpy(), gd["grad_stem_w"], atol=2e-6, rtol=1e-3)
+    np.testing.assert_allclose(st["lidar_encoder.encoder.point_mlp.0.weight"].grad.numpy(), gd["grad_lidar_w0"],
+                               atol=2e-6, rtol=1e-3)
+    for k, want in zip(gd["buf_keys"], gd["buf_digest"]):
+        assert digest_close(digest(st[str(k)].float()), want), str(k)
+    # confusion matrix / mIoU (trainer.py:18-37), integer-exact
+    conf = O.confusion_matrix(logits.detach(), labels)
+    assert np.array_equal(conf.numpy(), gd["confusion"])
+    assert abs(O.miou_from_confusion(conf)[1] - float(gd["miou"])) < 1e-12
+    # AdamW (trainer.py:56)
+    params = [st[k].detach() for k in keys]
+    grads = [st[k].grad for k in keys]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    O.adamw_step(params, grads, m, v, step=1)
+    for k, p, want, gdig in zip(keys, params, gd["adamw_digest"], gd["grad_digest"]):
+        if gdig[1] < 1e-5:
+            # conv biases in front of a train-mode BN have a mathematically zero gradient; what is
+            # left is rounding noise, which Adam's m/sqrt(v) normalisation turns into +-lr.
+            continue
+        assert digest_close(digest(p), want, rtol=1e-5), k
+
+
+def _lidar_state(seed):
+    full = state_template("weighted")
+    pre = "lidar_encoder.encoder."
+    sub = {k[len(pre):]: v for k, v in full.items() if k.startswith(pre)}
+    return O.randomize_state(sub, seed)
+
+
+@pytest.mark.parametrize("case", ("edge", "outside", "nan"))
+def test_lidar_edges(case):
+    gd = golden("lidar_edges.npz")
+    pts = torch.from_numpy(gd[f"{case}_points"])
+    flat, valid = O.bev_cell_index(pts, (16, 16))
+    assert np.array_equal(valid.numpy(), gd[f"{case}_valid"])
+    assert np.array_equal(flat.numpy()[valid.numpy()], gd[f"{case}_flat"][valid.numpy()])
+    for mode in (("eval",) if case == "nan" else ("eval", "train")):
+        st = O.clone_state(_lidar_state(3), requires_grad=(mode == "train"))
+        y = O.spatial_lidar_encoder(pts, st, "", (16, 16), training=(mode == "train"))
+        np.testing.assert_allclose(y.detach().numpy(), gd[f"{case}_{mode}_out"], atol=TOL, rtol=0)
+        if case == "outside":
+            assert float(y.abs().max()) == 0.0          # test_lidar_encoder.py:226-233
+        if mode == "train" and y.requires_grad:
+            up = torch.from_numpy(gd[f"{case}_upstream"])
+            (y * up).sum().backward()
+            for k in O.trainable_keys(st):
+                want = gd[f"{case}_grad_{k}"]
+                np.testing.assert_allclose(st[k].grad.numpy(), want, atol=5e-5 * max(1.0, np.abs(want).max()),
+                                           rtol=1e-3, err_msg=k)
+
+
+def test_scatter_tie_rule():
+    # SURVEY 8 a-5 probe: src [1,1,.5]->cell0, [0,0]->cell1 gives grads [.5,.5,0, 1/3,1/3]
+    src = torch.tensor([[1.0], [1.0], [0.5], [0.0], [0.0]], requires_grad=True)
+    idx = torch.tensor([0, 0, 0, 1, 1])
+    out = O._ScatterMaxZeroInit.apply(src, idx, 3)
+    assert out.flatten().tolist() == [1.0, 0.0, 0.0]
+    out.sum().backward()
+    np.testing.assert_allclose(src.grad.flatten().numpy(), [0.5, 0.5, 0.0, 1 / 3, 1 / 3], rtol=1e-6)
+
+
+def test_full_size_eval():
+    gd = golden("full_weighted_eval.npz")
+    st = _state("weighted", 2)
+    images, pts, _ = O.make_inputs(2, 256, 5000, 64, 2, pad_tail=300)
+    with torch.no_grad():
+        logits, mids = O.complete_model(images, pts, st, fusion_type="weighted", grid=(64, 64))
+    np.testing.assert_allclose(logits.numpy(), gd["logits"], atol=TOL, rtol=0)
+    safe = np.abs(gd["logits"][:, 0] - gd["logits"][:, 1]) > 10 * TOL
+    assert np.array_equal(logits.argmax(1).numpy()[safe], gd["argmax"][safe])
+    assert digest_close(digest(mids["camera_feat"]), gd["camera_feat_digest"])
+    assert digest_close(digest(mids["lidar_feat"]), gd["lidar_feat_digest"])
+
+
+def test_kd_step():
+    gd = golden("kd_step.npz")
+    t_st = _state("concat", 11)
+    s_st = _state("weighted", 12, grad=True)
+    images, pts, labels = O.make_inputs(B, HW, N, G, 4, pad_tail=40)
+    with torch.no_grad():
+        zt, mt = O.complete_model(images, pts, t_st, fusion_type="concat", grid=(G, G), training=False)
+    zs, ms = O.complete_model(images, pts, s_st, fusion_type="weighted", grid=(G, G), training=True)
+    total, parts = O.kd_loss(zs, ms, zt, mt, labels, torch.tensor([0.4, 3.5]), T=4.0, alpha=1.0, beta=1.0)
+    np.testing.assert_allclose(zt.numpy(), gd["teacher_logits"], atol=TOL, rtol=0)
+    assert abs(parts["ce"].item() - float(gd["ce"])) < 1e-5
+    assert abs(parts["kl"].item() - float(gd["kl"])) < 1e-6
+    assert abs((parts["mse_cam"] + parts["mse_lidar"]).item() - float(gd["mse"])) < 1e-5
+    assert abs(total.item() - float(gd["total"])) < 2e-5
+    total.backward()
+    for k, want in zip(gd["grad_keys"], gd["grad_digest"]):
+        assert digest_close(digest(s_st[str(k)].grad), want), str(k)
+
+
+def test_head_x4():
+    gd = golden("head_x4.npz")
+    st = state_template("concat")
+    for k in [k for k in st if k.startswith("head.")]:
+        del st[k]
+    def bn(p, c):
+        st[p + ".weight"] = torch.zeros(c); st[p + ".bias"] = torch.zeros(c)
+        st[p + ".running_mean"] = torch.zeros(c); st[p + ".running_var"] = torch.zeros(c)
+        st[p + ".num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    st["head.up1.0.weight"] = torch.zeros(256, 64, 4, 4); bn("head.up1.1", 64)
+    st["head.up2.0.weight"] = torch.zeros(64, 16, 4, 4); bn("head.up2.1", 16)
+    st["head.cls.weight"] = torch.zeros(3, 16, 3, 3); st["head.cls.bias"] = torch.zeros(3)
+    st = O.randomize_state(st, 21)
+    images, pts, _ = O.make_inputs(B, HW, N, G, 6)
+    with torch.no_grad():
+        z, _ = O.complete_model(images, pts, st, fusion_type="concat", grid=(G, G), output_mode="x4")
+    assert z.shape == (2, 3, 64, 64)               # test_lidar_encoder.py:293 (x4 of the 16x16 grid)
+    np.testing.assert_allclose(z.numpy(), gd["logits"], atol=TOL, rtol=0)
+
+
+def test_cosine_lr_matches_torch():
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-3)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=20, eta_min=1e-5)
+    for e in range(1, 21):
+        opt.step(); sch.step()
+        assert abs(opt.param_groups[0]["lr"] - O.cosine_lr(1e-3, e, 20)) < 1e-12
