@@ -1,0 +1,156 @@
+/* kd_hip.h -- C ABI of libkd_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * camera+LiDAR knowledge-distillation training step.
+ *
+ * The reference (KELVIN-ASU/Lightweight-Multi-Modal-Scene-Understanding-via-Knowledge-Distillation)
+ * has no native layer: its hot path is Python nn.Modules dispatching to ATen.  Each entry point
+ * below therefore replaces the ATen op sequence issued by the cited reference lines (paths are
+ * relative to the reference root).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated; the caller (PyTorch's caching allocator)
+ *     owns all memory including workspaces; the library never allocates and keeps no pointer;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no host synchronisation,
+ *     so every call is legal inside hipStreamBeginCapture / hipGraph replay;
+ *   - return 0 on success, < 0 for argument / shape / alignment / workspace errors, > 0 for a
+ *     hipError_t; kd_last_error_string() describes the last failure on the calling thread;
+ *   - activations are fp32 NHWC: a row-major matrix [M = B*H*W, C] with a row stride `ld` (floats);
+ *   - a "deferred" operand (x, sc, sh, act) means value = act(x*sc[c] + sh[c]); sc == NULL means
+ *     the tensor is already materialised; act: 0 none, 1 ReLU, 2 ReLU6;
+ *   - BatchNorm batch statistics travel as a slab `partial[rows][2][C]` of per-workgroup sums whose
+ *     row count is given by the matching kd_*_stat_rows() query (host function, no GPU work);
+ *     `pstride` is the slab's channel stride (== C unless the BN covers a slice of a wider slab).
+ */
+#ifndef KD_HIP_H
+#define KD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KD_ACT_NONE 0
+#define KD_ACT_RELU 1
+#define KD_ACT_RELU6 2
+
+int kd_version(void);
+const char* kd_arch(void);
+const char* kd_last_error_string(void);
+
+/* ---- 1x1 convolution = fp32-MFMA GEMM ------------------------------------------------------
+ * Replaces nn.Conv2d(k=1) / nn.Conv1d(k=1) forward and its data gradient:
+ * camera_encoder.py:24,39  fusion_module.py:12,29,116  lidar_encoder.py:29,32.
+ *   C[M,N] = Aeff[M,K] . W[N,K]^T (+ bias[N]) (+ addend[M,N])
+ *   pro 0: Aeff = A                      pro 1: Aeff = act(A*p0 + p1)         (p0/p1 = sc/sh [K])
+ *   pro 2: Aeff = p0*(A*mask(A2*p3+p4)) + p1*A2 + p2   (BN backward folded in: A = G, A2 = X raw,
+ *          p0/p1/p2 = al/be/ga from kd_bn_bwd_finalize, p3/p4 = sc/sh of the mask or NULL)
+ *   epi 0: store     epi 1: store + partial (sum, sum^2)      [forward, feeds kd_bn_finalize_train]
+ *   epi 2: C *= act'(X*esc+esh); partial (sum C, sum C*xhat)  [dgrad, feeds kd_bn_bwd_finalize]
+ * The dgrad call passes W = transposed weight [K_out=Cin][N_red=Cout] (kd_transpose). */
+int64_t kd_pwconv_stat_rows(int64_t M);
+int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, int pro, int pro_act,
+                   const float* p0, const float* p1, const float* p2, const float* p3, const float* p4,
+                   const float* W, const float* bias, float* C, int64_t ldc, const float* addend,
+                   int64_t ldadd, int epi, const float* X, int64_t ldx, const float* esc, const float* esh,
+                   const float* emean, const float* einv, int epi_act, float* partial, int64_t M, int K, int N,
+                   void* stream);
+/* weight gradient dW[N,K] = Deff[M,N]^T . Aeff[M,K] (split-M partial tiles in `ws`, fixed-order sum).
+ * d_mode 0: Deff = D; d_mode 2: Deff = al*(D*mask(X*msc+msh)) + be*X + ga.  a_mode 0/1 like pro 0/1. */
+size_t kd_pwconv_wgrad_ws_bytes(int64_t M, int N, int K);
+int kd_pwconv_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, int d_mode, int d_act,
+                    const float* al, const float* be, const float* ga, const float* msc, const float* msh,
+                    const float* A, int64_t lda, int a_mode, int a_act, const float* asc, const float* ash,
+                    float* dW, int64_t M, int N, int K, void* ws, size_t ws_bytes, void* stream);
+int kd_transpose(const float* in, float* out, int R, int C, void* stream);
+
+/* ---- stem 3x3/s2 conv (camera_encoder.py:63-67), NCHW image in, NHWC raw out, Cout == 32 ---- */
+int64_t kd_stem_stat_rows(int64_t npix_out);
+int kd_stem_conv_fwd(const float* x_nchw, const float* w, float* y_nhwc, float* partial, int B, int Cin, int H,
+                     int W, int Cout, void* stream);
+/* im2col (K padded to Kp, zeros) so that the stem weight gradient is kd_pwconv_wgrad with K = Kp. */
+int kd_stem_im2col(const float* x_nchw, float* col, int B, int Cin, int H, int W, int Kp, void* stream);
+
+/* ---- depthwise 3x3, pad 1, stride 1|2 (camera_encoder.py:30-35, fusion_module.py:25-27,78) ---- */
+int64_t kd_dwconv_stat_rows(int64_t npix_out, int C);
+int kd_dwconv3x3_fwd(const float* x, const float* sc, const float* sh, int act, const float* w, float* y,
+                     float* partial, int B, int H, int W, int C, int stride, void* stream);
+int64_t kd_dwconv_bwd_stat_rows(int64_t npix_in, int C);
+size_t kd_dwconv_bwd_ws_bytes(int64_t npix_out, int C);
+int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const float* be, const float* ga,
+                     const float* dsc, const float* dsh, int d_act, const float* x, const float* sc,
+                     const float* sh, int act, const float* mean, const float* invstd, const float* w, float* gx,
+                     float* partial, float* dw, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes,
+                     void* stream);
+
+/* ---- BatchNorm coefficient kernels (nn.BatchNorm1d/2d: eps 1e-5, momentum 0.1) ---------------- */
+int kd_bn_finalize_train(const float* partial, int rows, int C, int pstride, int64_t count, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                         int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                         void* stream);
+int kd_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, int C, float* mean, float* invstd, float* scale, float* shift, void* stream);
+int64_t kd_rowwise_stat_rows(int64_t M, int C);
+int kd_bn_act_apply(const float* x, int64_t ldx, const float* sc, const float* sh, int act, const float* res,
+                    int64_t ldr, float* out, int64_t ldo, int64_t M, int C, void* stream);
+int kd_bn_bwd_reduce(const float* D, int64_t ldd, const float* X, int64_t ldx, const float* sc, const float* sh,
+                     int act, const float* mean, const float* invstd, float* partial, int64_t M, int C,
+                     void* stream);
+int kd_bn_bwd_finalize(const float* partial, int rows, int C, int pstride, int64_t count, const float* gamma, const float* mean,
+                       const float* invstd, int training, float* dgamma, float* dbeta, float* al, float* be,
+                       float* ga, float* dbias, void* stream);
+
+/* ---- LiDAR branch (lidar_encoder.py:25-35,42-99) ----------------------------------------------- */
+int kd_lidar_l0_fwd(const float* pts, const float* w, const float* b, float* y, float* partial, int64_t P, int C,
+                    void* stream);
+size_t kd_lidar_l0_bwd_ws_bytes(int64_t P, int C);
+int kd_lidar_l0_bwd(const float* D, const float* Y, const float* al, const float* be, const float* ga,
+                    const float* pts, float* dwb, int64_t P, int C, void* ws, size_t ws_bytes, void* stream);
+int kd_lidar_scatter_max_fwd(const float* pts, const float* y, const float* sc, const float* sh, int act,
+                             float* grid, int B, int64_t N, int C, int H, int W, float x0, float x1, float y0,
+                             float y1, void* stream);
+int64_t kd_lidar_scatter_stat_rows(int64_t P, int C);
+size_t kd_lidar_scatter_bwd_ws_bytes(int B, int H, int W, int C);
+int kd_lidar_scatter_max_bwd(const float* pts, const float* y, const float* sc, const float* sh, int act,
+                             const float* grid, const float* dout, const float* mean, const float* invstd,
+                             float* G, float* partial, int B, int64_t N, int C, int H, int W, float x0, float x1,
+                             float y0, float y1, void* ws, size_t ws_bytes, void* stream);
+int kd_lidar_bev_index(const float* pts, int* cell, int64_t P, int H, int W, float x0, float x1, float y0,
+                       float y1, void* stream);
+
+/* ---- FPN resize, weighted-fusion tail, classifier (fusion_module.py:58-63,115-120,170-173) ----- */
+int kd_bilinear_accum_fwd(const float* in, const float* sc, const float* sh, int act, float* out, int accumulate,
+                          int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
+int kd_bilinear_bwd(const float* dout, const float* in, const float* sc, const float* sh, int act,
+                    const float* mean, const float* invstd, float* gin, float* partial, int B, int Hi, int Wi,
+                    int Ho, int Wo, int C, void* stream);
+int kd_weighted_fuse_fwd(const float* cat, const float* sc, const float* sh, const float* hraw, const float* w2,
+                         const float* b2, float* out, float* wts, int64_t M, int C, void* stream);
+size_t kd_weighted_fuse_bwd_ws_bytes(int64_t M, int C);
+int kd_weighted_fuse_bwd(const float* dout, const float* cat, const float* sc, const float* sh, const float* hraw,
+                         const float* w2, const float* wts, float* dcat, float* gh, float* dparams, int64_t M,
+                         int C, void* ws, size_t ws_bytes, void* stream);
+int kd_cls_conv_fwd(const float* x, const float* sc, const float* sh, int act, const float* w, const float* b,
+                    float* logits_nchw, int64_t M, int HW, int Cin, int NC, void* stream);
+size_t kd_cls_conv_bwd_ws_bytes(int64_t M, int Cin, int NC);
+int64_t kd_cls_conv_bwd_stat_rows(int64_t M, int Cin);
+int kd_cls_conv_bwd(const float* dlog_nchw, const float* x, const float* sc, const float* sh, int act,
+                    const float* mean, const float* invstd, const float* w, float* gx, float* partial, float* dwb,
+                    int64_t M, int HW, int Cin, int NC, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- losses, metric, optimiser (trainer.py:18-37,55-56,86-90; KD terms are build-defined) ------ */
+size_t kd_seg_loss_ws_bytes(int64_t npix);
+int kd_seg_loss_fwd_bwd(const float* zs, const float* zt, const int64_t* target, const float* class_w,
+                        int ignore_index, float T, float alpha, float gscale, const float* gscale_dev, float* losses,
+                        float* dzs, int B, int NC, int HW, void* ws, size_t ws_bytes, void* stream);
+size_t kd_mse_ws_bytes(int64_t n);
+int kd_mse_fwd_bwd(const float* a, const float* b, int64_t n, float gcoef, const float* gscale_dev, float* loss,
+                   float* da, void* ws, size_t ws_bytes, void* stream);
+int kd_argmax_confusion(const float* logits, const int64_t* target, int ignore_index, uint64_t* conf,
+                        int64_t* pred, int B, int NC, int HW, void* stream);
+int kd_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float ginv, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KD_HIP_H */

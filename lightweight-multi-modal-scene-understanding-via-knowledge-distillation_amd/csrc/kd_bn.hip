@@ -1,0 +1,217 @@
+// kd_bn.hip -- BatchNorm as per-channel coefficient kernels (nn.BatchNorm2d / BatchNorm1d semantics,
+// eps 1e-5, momentum 0.1: camera_encoder.py:25,33,40,65  lidar_encoder.py:27,30,33  fusion_module.py:13,27,30).
+//
+// The conv kernels leave per-block partial sums in a slab [rows][2][C]; the finalize kernels below
+// reduce them in fp64 in a fixed order (deterministic) and emit the coefficient vectors that the
+// NEXT kernel folds into its operand loads:
+//   forward : scale = gamma*invstd, shift = beta - mean*scale         (value = act(raw*scale+shift))
+//   backward: dy_raw = al*G + be*X + ga                                (G = dL/dact * act'(z))
+#include "kd_common.h"
+
+namespace {
+
+// grid.x = ceil(C/64); block (64, 4): 4 row lanes per channel
+__device__ __forceinline__ void reduce_slab2(const float* partial, int rows, int C, int pstride, int c, double& s1,
+                                             double& s2, double (*sm)[2][64]) {
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int r = threadIdx.y; r < rows; r += 4) {
+      a += (double)partial[((int64_t)r * 2 + 0) * pstride + c];
+      b += (double)partial[((int64_t)r * 2 + 1) * pstride + c];
+    }
+  sm[threadIdx.y][0][threadIdx.x] = a;
+  sm[threadIdx.y][1][threadIdx.x] = b;
+  __syncthreads();
+  s1 = sm[0][0][threadIdx.x] + sm[1][0][threadIdx.x] + sm[2][0][threadIdx.x] + sm[3][0][threadIdx.x];
+  s2 = sm[0][1][threadIdx.x] + sm[1][1][threadIdx.x] + sm[2][1][threadIdx.x] + sm[3][1][threadIdx.x];
+}
+
+__global__ void bn_finalize_train_kernel(const float* partial, int rows, int C, int pstride, double count, const float* gamma,
+                                         const float* beta, float eps, float momentum, float* running_mean,
+                                         float* running_var, int64_t* nbt, float* mean, float* invstd, float* scale,
+                                         float* shift) {
+  __shared__ double sm[4][2][64];
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  double s1, s2;
+  reduce_slab2(partial, rows, C, pstride, c, s1, s2, sm);
+  if (threadIdx.y != 0 || c >= C) return;
+  const double mu = s1 / count;
+  double var = s2 / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float inv = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float muf = (float)mu;
+  mean[c] = muf;
+  invstd[c] = inv;
+  const float sc = g * inv;
+  scale[c] = sc;
+  shift[c] = fmaf(-muf, sc, b);
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+  }
+  if (nbt && c == 0) *nbt += 1;
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int C, float* mean, float* invstd, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float inv = 1.f / sqrtf(rv[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * inv;
+  if (mean) mean[c] = rm[c];
+  if (invstd) invstd[c] = inv;
+  scale[c] = sc;
+  shift[c] = fmaf(-rm[c], sc, b);
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* partial, int rows, int C, int pstride, double count, const float* gamma,
+                                       const float* mean, const float* invstd, int training, float* dgamma,
+                                       float* dbeta, float* al, float* be, float* ga, float* dbias) {
+  __shared__ double sm[4][2][64];
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  double s1, s2;
+  reduce_slab2(partial, rows, C, pstride, c, s1, s2, sm);
+  if (threadIdx.y != 0 || c >= C) return;
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  const double g = gamma ? (double)gamma[c] : 1.0;
+  const double inv = (double)invstd[c], mu = (double)mean[c];
+  const double a = g * inv;
+  if (training) {
+    const double c1 = s1 / count, c2 = s2 / count;
+    al[c] = (float)a;
+    be[c] = (float)(-a * c2 * inv);
+    ga[c] = (float)(a * (c2 * inv * mu - c1));
+    if (dbias) dbias[c] = 0.f;          // sum_m dy_raw == 0 identically under batch statistics
+  } else {
+    al[c] = (float)a;
+    be[c] = 0.f;
+    ga[c] = 0.f;
+    if (dbias) dbias[c] = (float)(a * s1);
+  }
+}
+
+struct ApplyArgs {
+  const float* x; int64_t ldx; const float* sc; const float* sh; int act;
+  const float* res; int64_t ldr; float* out; int64_t ldo;
+  int64_t M; int C; int groups, slots;
+};
+__global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  if (slot >= a.slots) return;
+  const int c0 = gidx * 4;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4();
+  if (a.sc) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
+  for (int64_t m = (int64_t)blockIdx.x * a.slots + slot; m < a.M; m += (int64_t)gridDim.x * a.slots) {
+    float4 v = kd_ld4(a.x + m * a.ldx + c0);
+    v = kd_affine_act4(v, sc, sh, a.act);
+    if (a.res) {
+      const float4 r = kd_ld4(a.res + m * a.ldr + c0);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    kd_st4(a.out + m * a.ldo + c0, v);
+  }
+}
+
+struct BwdReduceArgs {
+  const float* D; int64_t ldd; const float* X; int64_t ldx; const float* sc; const float* sh; int act;
+  const float* mean; const float* invstd; float* partial; int64_t M; int C; int groups, slots;
+};
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdReduceArgs a) {
+  __shared__ float red[2 * 256 * 4];
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  const bool active = slot < a.slots;
+  const int c0 = gidx * 4;
+  float4 s1 = kd_zero4(), s2 = kd_zero4();
+  if (active) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4();
+    if (a.sc) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
+    const float4 mu = kd_ld4(a.mean + c0), inv = kd_ld4(a.invstd + c0);
+    for (int64_t m = (int64_t)blockIdx.x * a.slots + slot; m < a.M; m += (int64_t)gridDim.x * a.slots) {
+      const float4 d = kd_ld4(a.D + m * a.ldd + c0);
+      const float4 x = kd_ld4(a.X + m * a.ldx + c0);
+      const float gx = d.x * kd_act_mask(kd_affine(x.x, sc.x, sh.x), a.act);
+      const float gy = d.y * kd_act_mask(kd_affine(x.y, sc.y, sh.y), a.act);
+      const float gz = d.z * kd_act_mask(kd_affine(x.z, sc.z, sh.z), a.act);
+      const float gw = d.w * kd_act_mask(kd_affine(x.w, sc.w, sh.w), a.act);
+      s1.x += gx; s1.y += gy; s1.z += gz; s1.w += gw;
+      s2.x = fmaf(gx, (x.x - mu.x) * inv.x, s2.x);
+      s2.y = fmaf(gy, (x.y - mu.y) * inv.y, s2.y);
+      s2.z = fmaf(gz, (x.z - mu.z) * inv.z, s2.z);
+      s2.w = fmaf(gw, (x.w - mu.w) * inv.w, s2.w);
+    }
+  }
+  kd_st4(red + tid * 4, s1);
+  kd_st4(red + 1024 + tid * 4, s2);
+  __syncthreads();
+  for (int i = tid; i < 2 * a.C; i += 256) {
+    const int st = i / a.C, c = i % a.C;
+    float s = 0.f;
+    for (int sl = 0; sl < a.slots; ++sl) s += red[st * 1024 + (sl * a.groups + c / 4) * 4 + (c & 3)];
+    a.partial[((int64_t)blockIdx.x * 2 + st) * a.C + c] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Batch statistics -> forward coefficients; updates running stats / num_batches_tracked in place
+// (pass null to skip).  partial: [rows][2][C] holding (sum, sum of squares) over `count` samples.
+int kd_bn_finalize_train(const float* partial, int rows, int C, int pstride, int64_t count, const float* gamma, const float* beta,
+                         float eps, float momentum, float* running_mean, float* running_var, int64_t* nbt,
+                         float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  KD_REQUIRE(partial && rows > 0 && C > 0 && pstride >= C && count > 0 && mean && invstd && scale && shift, KD_ERR_ARG, "kd_bn_finalize_train: bad args");
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 63) / 64), dim3(64, 4), 0, (hipStream_t)stream, partial, rows,
+                     C, pstride, (double)count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd, scale,
+                     shift);
+  return kd_check_launch("kd_bn_finalize_train");
+}
+
+int kd_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, int C, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  KD_REQUIRE(running_mean && running_var && scale && shift && C > 0, KD_ERR_ARG, "kd_bn_eval_coeffs: bad args");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, C, mean, invstd, scale, shift);
+  return kd_check_launch("kd_bn_eval_coeffs");
+}
+
+int64_t kd_rowwise_stat_rows(int64_t M, int C) { return kd_cg_layout(M, C).grid; }
+
+// out = act(x*sc+sh) (+ res).  sc == null: identity affine.
+int kd_bn_act_apply(const float* x, int64_t ldx, const float* sc, const float* sh, int act, const float* res,
+                    int64_t ldr, float* out, int64_t ldo, int64_t M, int C, void* stream) {
+  KD_REQUIRE(x && out && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, KD_ERR_ARG, "kd_bn_act_apply: bad args (C=%d)", C);
+  KD_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && (!res || ldr % 4 == 0), KD_ERR_SHAPE, "kd_bn_act_apply: ld must be a multiple of 4");
+  const KdCgLayout l = kd_cg_layout(M, C);
+  ApplyArgs a{x, ldx, sc, sh, act, res, ldr, out, ldo, M, C, l.groups, l.slots};
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  return kd_check_launch("kd_bn_act_apply");
+}
+
+// partial[grid][2][C] = (sum G, sum G*xhat) with G = D * act'(X*sc+sh), xhat = (X-mean)*invstd.
+int kd_bn_bwd_reduce(const float* D, int64_t ldd, const float* X, int64_t ldx, const float* sc, const float* sh,
+                     int act, const float* mean, const float* invstd, float* partial, int64_t M, int C, void* stream) {
+  KD_REQUIRE(D && X && mean && invstd && partial && M > 0 && C % 4 == 0 && C <= 1024, KD_ERR_ARG, "kd_bn_bwd_reduce: bad args");
+  KD_REQUIRE(act == KD_ACT_NONE || (sc && sh), KD_ERR_ARG, "kd_bn_bwd_reduce: mask needs sc/sh");
+  const KdCgLayout l = kd_cg_layout(M, C);
+  BwdReduceArgs a{D, ldd, X, ldx, sc, sh, act, mean, invstd, partial, M, C, l.groups, l.slots};
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  return kd_check_launch("kd_bn_bwd_reduce");
+}
+
+int kd_bn_bwd_finalize(const float* partial, int rows, int C, int pstride, int64_t count, const float* gamma, const float* mean,
+                       const float* invstd, int training, float* dgamma, float* dbeta, float* al, float* be,
+                       float* ga, float* dbias, void* stream) {
+  KD_REQUIRE(partial && rows > 0 && C > 0 && pstride >= C && count > 0 && mean && invstd && al && be && ga, KD_ERR_ARG, "kd_bn_bwd_finalize: bad args");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64, 4), 0, (hipStream_t)stream, partial, rows, C,
+                     pstride, (double)count, gamma, mean, invstd, training, dgamma, dbeta, al, be, ga, dbias);
+  return kd_check_launch("kd_bn_bwd_finalize");
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// kd_common.h -- shared device helpers for the gfx950 (MI355X / CDNA4) KD kernels.
+//
+// Conventions used by every kernel in this directory
+//   * activations are fp32 NHWC, addressed as a row-major matrix [M = B*H*W, C] with a row
+//     stride `ld` (floats) so that a tensor may live inside a wider concat buffer;
+//   * a "deferred" operand is a RAW conv output plus per-channel (scale, shift) and an
+//     activation id: value = act(raw * scale + shift).  BatchNorm + activation are never
+//     materialised between two convolutions -- the consumer applies them on load;
+//   * BatchNorm batch statistics are produced by the conv kernel's epilogue as per-block
+//     partial sums in a slab [rows][2][C] and reduced (in fp64, fixed order => deterministic)
+//     by kd_bn_finalize_train.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KD_ACT_NONE 0
+#define KD_ACT_RELU 1
+#define KD_ACT_RELU6 2
+
+#define KD_OK 0
+#define KD_ERR_ARG (-1)
+#define KD_ERR_ALIGN (-2)
+#define KD_ERR_WORKSPACE (-3)
+#define KD_ERR_SHAPE (-4)
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+void kd_set_error(const char* fmt, ...);
+int kd_check_launch(const char* what);
+
+#define KD_REQUIRE(cond, code, ...)        \
+  do {                                     \
+    if (!(cond)) {                         \
+      kd_set_error(__VA_ARGS__);           \
+      return (code);                       \
+    }                                      \
+  } while (0)
+
+static inline bool kd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// z = raw*scale + shift, as ONE fused multiply-add: forward, backward masks and the scatter-max
+// tie test all call this, so a recomputed value is bit-identical to the one used in the forward.
+__device__ __forceinline__ float kd_affine(float raw, float sc, float sh) { return fmaf(raw, sc, sh); }
+
+__device__ __forceinline__ float kd_act(float z, int act) {
+  if (act == KD_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (act == KD_ACT_RELU6) return z > 0.f ? (z < 6.f ? z : 6.f) : 0.f;
+  return z;
+}
+// derivative mask of kd_act at pre-activation z (ATen threshold_backward / hardtanh_backward:
+// strict inequalities on both sides)
+__device__ __forceinline__ float kd_act_mask(float z, int act) {
+  if (act == KD_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == KD_ACT_RELU6) return (z > 0.f && z < 6.f) ? 1.f : 0.f;
+  return 1.f;
+}
+
+__device__ __forceinline__ float4 kd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void kd_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 kd_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+__device__ __forceinline__ float4 kd_affine_act4(float4 x, float4 sc, float4 sh, int act) {
+  float4 r;
+  r.x = kd_act(kd_affine(x.x, sc.x, sh.x), act);
+  r.y = kd_act(kd_affine(x.y, sc.y, sh.y), act);
+  r.z = kd_act(kd_affine(x.z, sc.z, sh.z), act);
+  r.w = kd_act(kd_affine(x.w, sc.w, sh.w), act);
+  return r;
+}
+
+// backward operand: dy_raw = al*(d*mask(z)) + be*x + ga with z = x*sc+sh  (al/be/ga from
+// kd_bn_bwd_finalize).  With act == NONE the mask is 1 and sc/sh are not read.
+__device__ __forceinline__ float kd_bwd_operand(float d, float x, float al, float be, float ga,
+                                                float sc, float sh, int act) {
+  float g = d * kd_act_mask(kd_affine(x, sc, sh), act);
+  return fmaf(al, g, fmaf(be, x, ga));
+}
+
+__device__ __forceinline__ float kd_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// out[i] = sum_s slab[s][i], s in fixed order (deterministic); defined in kd_runtime.hip
+int kd_slab_reduce_launch(const float* slab, int nsplit, int64_t n, float* out, hipStream_t st);
+
+// Generic "channel-group x row-slot" thread layout used by the HBM-bound NHWC kernels:
+// a thread owns 4 consecutive channels (one float4) and walks rows with a grid stride.
+struct KdCgLayout {
+  int groups;      // C / 4
+  int slots;       // row slots per block = 256 / groups (>= 1)
+  int grid;        // blocks
+};
+static inline KdCgLayout kd_cg_layout(int64_t rows, int C, int max_blocks = 2048) {
+  KdCgLayout l;
+  l.groups = C / 4;
+  l.slots = 256 / l.groups;
+  if (l.slots < 1) l.slots = 1;
+  int64_t need = (rows + l.slots - 1) / l.slots;
+  l.grid = (int)(need < max_blocks ? need : max_blocks);
+  if (l.grid < 1) l.grid = 1;
+  return l;
+}

@@ -1,0 +1,294 @@
+// kd_lidar.hip -- LiDAR branch kernels that are not plain GEMMs (lidar_encoder.py:42-99):
+//   * point_mlp layer 0 (Conv1d 4->64, k=1, bias): K=4 is VALU work, not MFMA work;
+//   * BEV binning + scatter-max of the activated 128-ch point features into the [B,H,W,C] grid
+//     (== zeros.scatter_reduce_(amax, include_self=False) because post-ReLU values are >= 0, so an
+//     unsigned-integer atomicMax on the fp32 bit pattern into a zero grid is exact and
+//     order-independent => bitwise deterministic);
+//   * its backward with ATen's even tie-split rule.
+// Layers 1 and 2 of the point MLP (64->128->128) go through kd_pwconv_gemm with M = B*N points.
+#include "kd_common.h"
+
+namespace {
+
+struct BevGeom { float x0, xd, y0, yd; int H, W; };
+
+// lidar_encoder.py:46-55,69-71 -- arithmetic kept in the reference's order, no contraction
+__device__ __forceinline__ bool bev_cell(const float4 pt, const BevGeom g, int& cell) {
+  const float xn = __fdiv_rn(__fsub_rn(pt.x, g.x0), g.xd);
+  const float yn = __fdiv_rn(__fsub_rn(pt.y, g.y0), g.yd);
+  const bool valid = (xn >= 0.f) && (xn <= 1.f) && (yn >= 0.f) && (yn <= 1.f);   // NaN => false
+  if (!valid) { cell = -1; return false; }
+  long long ix = (long long)__fmul_rn(xn, (float)(g.W - 1));
+  long long iy = (long long)__fmul_rn(yn, (float)(g.H - 1));
+  ix = ix < 0 ? 0 : (ix > g.W - 1 ? g.W - 1 : ix);
+  iy = iy < 0 ? 0 : (iy > g.H - 1 ? g.H - 1 : iy);
+  cell = (int)(iy * g.W + ix);
+  return true;
+}
+
+// ---- layer 0: y[p, co] = b[co] + sum_i w[co, i] * pt[p, i] -------------------------------------
+struct L0Args {
+  const float* pts; const float* w; const float* b; float* y; float* partial;
+  int64_t P; int C; int groups, slots;
+};
+__global__ __launch_bounds__(256) void lidar_l0_fwd_kernel(L0Args a) {
+  __shared__ float red[2 * 256 * 4];
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  const bool active = slot < a.slots;
+  const int c0 = gidx * 4;
+  float4 wr[4], bias = kd_zero4();
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr[j] = kd_ld4(a.w + (c0 + j) * 4);
+    if (a.b) bias = kd_ld4(a.b + c0);
+  }
+  float4 s1 = kd_zero4(), s2 = kd_zero4();
+  if (active) {
+    for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < a.P; p += (int64_t)gridDim.x * a.slots) {
+      const float4 pt = kd_ld4(a.pts + p * 4);
+      float4 v;
+      v.x = fmaf(wr[0].w, pt.w, fmaf(wr[0].z, pt.z, fmaf(wr[0].y, pt.y, fmaf(wr[0].x, pt.x, bias.x))));
+      v.y = fmaf(wr[1].w, pt.w, fmaf(wr[1].z, pt.z, fmaf(wr[1].y, pt.y, fmaf(wr[1].x, pt.x, bias.y))));
+      v.z = fmaf(wr[2].w, pt.w, fmaf(wr[2].z, pt.z, fmaf(wr[2].y, pt.y, fmaf(wr[2].x, pt.x, bias.z))));
+      v.w = fmaf(wr[3].w, pt.w, fmaf(wr[3].z, pt.z, fmaf(wr[3].y, pt.y, fmaf(wr[3].x, pt.x, bias.w))));
+      kd_st4(a.y + p * a.C + c0, v);
+      s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+      s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+    }
+  }
+  if (a.partial) {
+    kd_st4(red + tid * 4, s1);
+    kd_st4(red + 1024 + tid * 4, s2);
+    __syncthreads();
+    for (int i = tid; i < 2 * a.C; i += 256) {
+      const int st = i / a.C, c = i % a.C;
+      float s = 0.f;
+      for (int sl = 0; sl < a.slots; ++sl) s += red[st * 1024 + (sl * a.groups + c / 4) * 4 + (c & 3)];
+      a.partial[((int64_t)blockIdx.x * 2 + st) * a.C + c] = s;
+    }
+  }
+}
+
+// layer-0 backward: dw[co,i] = sum_p dyeff[p,co]*pt[p,i]; db[co] = sum_p dyeff[p,co]
+struct L0BwdArgs {
+  const float* D; const float* Y; const float* al; const float* be; const float* ga;
+  const float* pts; float* slab;     // slab [grid][C*5]: dw (C*4) then db (C)
+  int64_t P; int C; int groups, slots;
+};
+__global__ __launch_bounds__(256) void lidar_l0_bwd_kernel(L0BwdArgs a) {
+  __shared__ float red[256 * 4];
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  const bool active = slot < a.slots;
+  const int c0 = gidx * 4;
+  float4 acc[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) acc[t] = kd_zero4();
+  if (active) {
+    const float4 al = kd_ld4(a.al + c0), be = kd_ld4(a.be + c0), ga = kd_ld4(a.ga + c0);
+    for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < a.P; p += (int64_t)gridDim.x * a.slots) {
+      const float4 d = kd_ld4(a.D + p * a.C + c0), y = kd_ld4(a.Y + p * a.C + c0);
+      float4 g;
+      g.x = kd_bwd_operand(d.x, y.x, al.x, be.x, ga.x, 0.f, 0.f, KD_ACT_NONE);
+      g.y = kd_bwd_operand(d.y, y.y, al.y, be.y, ga.y, 0.f, 0.f, KD_ACT_NONE);
+      g.z = kd_bwd_operand(d.z, y.z, al.z, be.z, ga.z, 0.f, 0.f, KD_ACT_NONE);
+      g.w = kd_bwd_operand(d.w, y.w, al.w, be.w, ga.w, 0.f, 0.f, KD_ACT_NONE);
+      const float4 pt = kd_ld4(a.pts + p * 4);
+      const float pv[4] = {pt.x, pt.y, pt.z, pt.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i].x = fmaf(g.x, pv[i], acc[i].x); acc[i].y = fmaf(g.y, pv[i], acc[i].y);
+        acc[i].z = fmaf(g.z, pv[i], acc[i].z); acc[i].w = fmaf(g.w, pv[i], acc[i].w);
+      }
+      acc[4].x += g.x; acc[4].y += g.y; acc[4].z += g.z; acc[4].w += g.w;
+    }
+  }
+  for (int t = 0; t < 5; ++t) {
+    __syncthreads();
+    kd_st4(red + tid * 4, acc[t]);
+    __syncthreads();
+    for (int c = tid; c < a.C; c += 256) {
+      float s = 0.f;
+      for (int sl = 0; sl < a.slots; ++sl) s += red[(sl * a.groups + c / 4) * 4 + (c & 3)];
+      const int64_t o = (int64_t)blockIdx.x * a.C * 5;
+      if (t < 4) a.slab[o + c * 4 + t] = s; else a.slab[o + a.C * 4 + c] = s;
+    }
+  }
+}
+
+// ---- scatter-max ---------------------------------------------------------------------------------
+struct ScatArgs {
+  const float* pts; const float* y; const float* sc; const float* sh; int act;   // deferred [P, C]
+  float* grid;                      // [B, H*W, C], zero-initialised by the caller entry point
+  unsigned* cnt;                    // bwd: tie counts [B*H*W*C]
+  const float* dout;                // bwd: dL/dgrid [B, H*W, C]
+  const float* mean; const float* invstd;
+  float* G; float* partial;
+  int B; int64_t N; int C; BevGeom geo; int groups, slots; int pass;
+};
+
+__global__ __launch_bounds__(256) void scatter_max_fwd_kernel(ScatArgs a) {
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  if (slot >= a.slots) return;
+  const int c0 = gidx * 4;
+  const float4 sc = kd_ld4(a.sc + c0), sh = kd_ld4(a.sh + c0);
+  const int64_t P = (int64_t)a.B * a.N;
+  const int HW = a.geo.H * a.geo.W;
+  for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < P; p += (int64_t)gridDim.x * a.slots) {
+    int cell;
+    if (!bev_cell(kd_ld4(a.pts + p * 4), a.geo, cell)) continue;
+    const float4 v = kd_affine_act4(kd_ld4(a.y + p * a.C + c0), sc, sh, a.act);
+    unsigned* dst = reinterpret_cast<unsigned*>(a.grid + ((p / a.N) * HW + cell) * a.C + c0);
+    if (v.x > 0.f) atomicMax(dst + 0, __float_as_uint(v.x));
+    if (v.y > 0.f) atomicMax(dst + 1, __float_as_uint(v.y));
+    if (v.z > 0.f) atomicMax(dst + 2, __float_as_uint(v.z));
+    if (v.w > 0.f) atomicMax(dst + 3, __float_as_uint(v.w));
+  }
+}
+
+// pass 0: count ties per (cell, channel); pass 1: G = tie ? dout/cnt : 0, plus BN-backward sums.
+__global__ __launch_bounds__(256) void scatter_max_bwd_kernel(ScatArgs a) {
+  __shared__ float red[2 * 256 * 4];
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  const bool active = slot < a.slots;
+  const int c0 = gidx * 4;
+  float4 s1 = kd_zero4(), s2 = kd_zero4();
+  if (active) {
+    const float4 sc = kd_ld4(a.sc + c0), sh = kd_ld4(a.sh + c0);
+    float4 mu = kd_zero4(), inv = kd_zero4();
+    if (a.pass == 1) { mu = kd_ld4(a.mean + c0); inv = kd_ld4(a.invstd + c0); }
+    const int64_t P = (int64_t)a.B * a.N;
+    const int HW = a.geo.H * a.geo.W;
+    for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < P; p += (int64_t)gridDim.x * a.slots) {
+      int cell;
+      const bool valid = bev_cell(kd_ld4(a.pts + p * 4), a.geo, cell);
+      float4 g = kd_zero4();
+      if (valid) {
+        const float4 yr = kd_ld4(a.y + p * a.C + c0);
+        const float4 v = kd_affine_act4(yr, sc, sh, a.act);
+        const int64_t o = ((p / a.N) * HW + cell) * a.C + c0;
+        const float4 mx = kd_ld4(a.grid + o);
+        const bool hx = v.x > 0.f && v.x == mx.x, hy = v.y > 0.f && v.y == mx.y;
+        const bool hz = v.z > 0.f && v.z == mx.z, hw = v.w > 0.f && v.w == mx.w;
+        if (a.pass == 0) {
+          if (hx) atomicAdd(a.cnt + o + 0, 1u);
+          if (hy) atomicAdd(a.cnt + o + 1, 1u);
+          if (hz) atomicAdd(a.cnt + o + 2, 1u);
+          if (hw) atomicAdd(a.cnt + o + 3, 1u);
+        } else if (hx || hy || hz || hw) {
+          const float4 d = kd_ld4(a.dout + o);
+          const uint4 n = *reinterpret_cast<const uint4*>(a.cnt + o);
+          if (hx) g.x = d.x / (float)n.x;
+          if (hy) g.y = d.y / (float)n.y;
+          if (hz) g.z = d.z / (float)n.z;
+          if (hw) g.w = d.w / (float)n.w;
+          s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+          s2.x = fmaf(g.x, (yr.x - mu.x) * inv.x, s2.x);
+          s2.y = fmaf(g.y, (yr.y - mu.y) * inv.y, s2.y);
+          s2.z = fmaf(g.z, (yr.z - mu.z) * inv.z, s2.z);
+          s2.w = fmaf(g.w, (yr.w - mu.w) * inv.w, s2.w);
+        }
+      }
+      if (a.pass == 1) kd_st4(a.G + p * a.C + c0, g);
+    }
+  }
+  if (a.pass == 1) {
+    kd_st4(red + tid * 4, s1);
+    kd_st4(red + 1024 + tid * 4, s2);
+    __syncthreads();
+    for (int i = tid; i < 2 * a.C; i += 256) {
+      const int st = i / a.C, c = i % a.C;
+      float s = 0.f;
+      for (int sl = 0; sl < a.slots; ++sl) s += red[st * 1024 + (sl * a.groups + c / 4) * 4 + (c & 3)];
+      a.partial[((int64_t)blockIdx.x * 2 + st) * a.C + c] = s;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int kd_lidar_l0_fwd(const float* pts, const float* w, const float* b, float* y, float* partial, int64_t P, int C,
+                    void* stream) {
+  KD_REQUIRE(pts && w && y && P > 0 && C % 4 == 0 && C <= 1024, KD_ERR_ARG, "kd_lidar_l0_fwd: bad args");
+  const KdCgLayout l = kd_cg_layout(P, C);
+  L0Args a{pts, w, b, y, partial, P, C, l.groups, l.slots};
+  hipLaunchKernelGGL(lidar_l0_fwd_kernel, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  return kd_check_launch("kd_lidar_l0_fwd");
+}
+
+size_t kd_lidar_l0_bwd_ws_bytes(int64_t P, int C) { return (size_t)kd_cg_layout(P, C).grid * C * 5 * sizeof(float); }
+
+// dwb: [C*4] weight gradient followed by [C] bias gradient.
+int kd_lidar_l0_bwd(const float* D, const float* Y, const float* al, const float* be, const float* ga,
+                    const float* pts, float* dwb, int64_t P, int C, void* ws, size_t ws_bytes, void* stream) {
+  KD_REQUIRE(D && Y && al && be && ga && pts && dwb && ws && P > 0 && C % 4 == 0, KD_ERR_ARG, "kd_lidar_l0_bwd: bad args");
+  const KdCgLayout l = kd_cg_layout(P, C);
+  KD_REQUIRE(ws_bytes >= (size_t)l.grid * C * 5 * sizeof(float), KD_ERR_WORKSPACE, "kd_lidar_l0_bwd: workspace too small");
+  L0BwdArgs a{D, Y, al, be, ga, pts, (float*)ws, P, C, l.groups, l.slots};
+  hipLaunchKernelGGL(lidar_l0_bwd_kernel, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  int rc = kd_check_launch("kd_lidar_l0_bwd");
+  if (rc) return rc;
+  return kd_slab_reduce_launch((const float*)ws, l.grid, (int64_t)C * 5, dwb, (hipStream_t)stream);
+}
+
+// grid[B,H,W,C] = scatter-max of act(y*sc+sh) over the valid points; zeroes `grid` first.
+int kd_lidar_scatter_max_fwd(const float* pts, const float* y, const float* sc, const float* sh, int act,
+                             float* grid, int B, int64_t N, int C, int H, int W, float x0, float x1, float y0,
+                             float y1, void* stream) {
+  KD_REQUIRE(pts && y && sc && sh && grid && B > 0 && N > 0 && C % 4 == 0 && C <= 1024, KD_ERR_ARG, "kd_lidar_scatter_max_fwd: bad args");
+  KD_REQUIRE(act == KD_ACT_RELU || act == KD_ACT_RELU6, KD_ERR_ARG, "kd_lidar_scatter_max_fwd: needs a non-negative activation");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(grid, 0, (size_t)B * H * W * C * sizeof(float), st);
+  KD_REQUIRE(e == hipSuccess, (int)e, "kd_lidar_scatter_max_fwd: memset failed: %s", hipGetErrorString(e));
+  const KdCgLayout l = kd_cg_layout((int64_t)B * N, C, 4096);
+  ScatArgs a{pts, y, sc, sh, act, grid, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, C,
+             BevGeom{x0, x1 - x0, y0, y1 - y0, H, W}, l.groups, l.slots, 0};
+  hipLaunchKernelGGL(scatter_max_fwd_kernel, dim3(l.grid), dim3(256), 0, st, a);
+  return kd_check_launch("kd_lidar_scatter_max_fwd");
+}
+
+int64_t kd_lidar_scatter_stat_rows(int64_t P, int C) { return kd_cg_layout(P, C, 4096).grid; }
+size_t kd_lidar_scatter_bwd_ws_bytes(int B, int H, int W, int C) { return (size_t)B * H * W * C * sizeof(unsigned); }
+
+// G[P,C] = dL/d(act(bn(y))) * relu'(.)  under the even tie-split rule; partial = (sum G, sum G*xhat).
+int kd_lidar_scatter_max_bwd(const float* pts, const float* y, const float* sc, const float* sh, int act,
+                             const float* grid, const float* dout, const float* mean, const float* invstd, float* G,
+                             float* partial, int B, int64_t N, int C, int H, int W, float x0, float x1, float y0,
+                             float y1, void* ws, size_t ws_bytes, void* stream) {
+  KD_REQUIRE(pts && y && sc && sh && grid && dout && mean && invstd && G && partial && ws, KD_ERR_ARG, "kd_lidar_scatter_max_bwd: bad args");
+  const size_t need = (size_t)B * H * W * C * sizeof(unsigned);
+  KD_REQUIRE(ws_bytes >= need, KD_ERR_WORKSPACE, "kd_lidar_scatter_max_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(ws, 0, need, st);
+  KD_REQUIRE(e == hipSuccess, (int)e, "kd_lidar_scatter_max_bwd: memset failed: %s", hipGetErrorString(e));
+  const KdCgLayout l = kd_cg_layout((int64_t)B * N, C, 4096);
+  ScatArgs a{pts, y, sc, sh, act, const_cast<float*>(grid), (unsigned*)ws, dout, mean, invstd, G, partial, B, N, C,
+             BevGeom{x0, x1 - x0, y0, y1 - y0, H, W}, l.groups, l.slots, 0};
+  hipLaunchKernelGGL(scatter_max_bwd_kernel, dim3(l.grid), dim3(256), 0, st, a);
+  a.pass = 1;
+  hipLaunchKernelGGL(scatter_max_bwd_kernel, dim3(l.grid), dim3(256), 0, st, a);
+  return kd_check_launch("kd_lidar_scatter_max_bwd");
+}
+
+// cell[p] = flat BEV cell index (iy*W+ix) or -1 for invalid points: exposed for the integer parity tests.
+__global__ void bev_index_kernel(const float* pts, int* cell, int64_t P, BevGeom g) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int c;
+  bev_cell(kd_ld4(pts + p * 4), g, c);
+  cell[p] = c;
+}
+int kd_lidar_bev_index(const float* pts, int* cell, int64_t P, int H, int W, float x0, float x1, float y0, float y1,
+                       void* stream) {
+  KD_REQUIRE(pts && cell && P > 0, KD_ERR_ARG, "kd_lidar_bev_index: bad args");
+  hipLaunchKernelGGL(bev_index_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts, cell,
+                     P, BevGeom{x0, x1 - x0, y0, y1 - y0, H, W});
+  return kd_check_launch("kd_lidar_bev_index");
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+"""Loss / metric Functions of the KD step (device-side values, no host sync).
+
+  seg_loss      : weighted CE with ignore_index (trainer.py:55,88), optionally + alpha*T^2*KL to a
+                  teacher's logits -- value and dL/dlogits produced by one fused HIP call
+  feature_mse   : F.mse_loss forward + gradient
+  kd_objective  : CE + alpha*T^2*KL + beta*(MSE(cam) + MSE(lidar))   (the
+                  reference has no KD code -- this definition is the build's specification)
+  confusion     : argmax + confusion matrix of SegmentationMetrics.update (trainer.py:18-26)
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .lib import KDError, lib
+from .ops import P, stream
+
+
+class _SegLossFn(torch.autograd.Function):
+    """forward: loss values only; backward: one more fused call that writes dL/dlogits scaled by the
+    upstream gradient read from device memory (no host sync, no extra elementwise pass)."""
+
+    @staticmethod
+    def _call(zs, zt, target, class_w, ignore_index, T, alpha, gdev, losses, dzs):
+        B, NC, H, W = zs.shape
+        nbytes = lib.kd_seg_loss_ws_bytes(B * H * W)
+        ws = ops.workspace(nbytes, zs.device)
+        lib.call("kd_seg_loss_fwd_bwd", P(zs), P(zt), P(target), P(class_w), int(ignore_index), float(T), float(alpha),
+                 1.0, P(gdev), P(losses), P(dzs), B, NC, H * W, P(ws), nbytes, stream())
+
+    @staticmethod
+    def forward(ctx, zs, zt, target, class_w, ignore_index, T, alpha):
+        ops.require_gpu_tensor(zs, "seg_loss")
+        zs_c = zs.detach().contiguous()
+        zt_c = None if zt is None else zt.detach().contiguous()
+        target = target.contiguous()
+        if target.dtype != torch.int64:
+            raise KDError("segmentation target must be int64")
+        losses = torch.empty(4, device=zs.device, dtype=torch.float32)
+        _SegLossFn._call(zs_c, zt_c, target, class_w, ignore_index, T, alpha, None, losses, None)
+        ctx.args = (zs_c, zt_c, target, class_w, ignore_index, T, alpha)
+        kl = losses[1]
+        ctx.mark_non_differentiable(kl)
+        return losses[0], kl
+
+    @staticmethod
+    def backward(ctx, g_ce, _g_kl):
+        # the gradient through `ce` is d(CE + alpha*T^2*KL)/dzs (kd_objective adds KL's value separately)
+        zs_c, zt_c, target, class_w, ignore_index, T, alpha = ctx.args
+        losses = torch.empty(4, device=zs_c.device, dtype=torch.float32)
+        dzs = torch.empty_like(zs_c)
+        g = g_ce.contiguous().view(1)
+        _SegLossFn._call(zs_c, zt_c, target, class_w, ignore_index, T, alpha, g, losses, dzs)
+        return dzs, None, None, None, None, None, None
+
+
+def seg_loss(logits, target, class_weights: Optional[torch.Tensor] = None, ignore_index: int = -1,
+             teacher_logits: Optional[torch.Tensor] = None, T: float = 4.0, alpha: float = 1.0):
+    """-> (ce, kl).  The gradient that flows back through `ce` is that of ce + alpha*T^2*kl
+    (kl is returned for logging / for adding its VALUE to the total)."""
+    if teacher_logits is None:
+        alpha = 0.0
+    return _SegLossFn.apply(logits, teacher_logits, target, class_weights, ignore_index, T, alpha)
+
+
+class _MSEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ops.require_gpu_tensor(a, "feature_mse")
+        am, _ = ops.nhwc_view(a.detach())
+        bm, _ = ops.nhwc_view(b.detach())
+        n = am.numel()
+        loss = torch.empty(1, device=a.device, dtype=torch.float32)
+        nbytes = lib.kd_mse_ws_bytes(n)
+        ws = ops.workspace(nbytes, a.device)
+        lib.call("kd_mse_fwd_bwd", P(am), P(bm), n, 0.0, None, P(loss), None, P(ws), nbytes, stream())
+        ctx.am, ctx.bm = am, bm
+        ctx.geom = (a.shape[0], a.shape[2], a.shape[3])
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        am, bm = ctx.am, ctx.bm
+        n = am.numel()
+        da = torch.empty_like(am)
+        nbytes = lib.kd_mse_ws_bytes(n)
+        ws = ops.workspace(nbytes, am.device)
+        lib.call("kd_mse_fwd_bwd", P(am), P(bm), n, 2.0 / n, P(g.contiguous().view(1)), None, P(da), P(ws), nbytes, stream())
+        return ops.nchw_from_matrix(da, ctx.geom), None
+
+
+def feature_mse(student_feat, teacher_feat):
+    return _MSEFn.apply(student_feat, teacher_feat)
+
+
+def kd_objective(student_logits, student_mids: Dict[str, torch.Tensor], teacher_logits, teacher_mids, target,
+                 class_weights=None, T: float = 4.0, alpha: float = 1.0, beta: float = 1.0, ignore_index: int = -1):
+    """total = CE + alpha*T^2*KL + beta*(MSE(camera_feat) + MSE(lidar_feat)); returns (total, parts)."""
+    ce, kl = seg_loss(student_logits, target, class_weights, ignore_index, teacher_logits, T, alpha)
+    mse_c = feature_mse(student_mids["camera_feat"], teacher_mids["camera_feat"])
+    mse_l = feature_mse(student_mids["lidar_feat"], teacher_mids["lidar_feat"])
+    # `ce` carries the CE+KL gradient; add KL's value without a second gradient path
+    total = ce + (alpha * T * T) * kl.detach() + beta * (mse_c + mse_l)
+    return total, {"ce": ce.detach(), "kl": kl.detach(), "mse_cam": mse_c.detach(), "mse_lidar": mse_l.detach()}
+
+
+def confusion(logits, target, num_classes: int = 2, ignore_index: int = -1, out: Optional[torch.Tensor] = None):
+    """Accumulates into (or creates) an int64 [C, C] device confusion matrix; returns (conf, argmax)."""
+    ops.require_gpu_tensor(logits, "confusion")
+    z = logits.detach().contiguous()
+    B, NC, H, W = z.shape
+    if out is None:
+        out = torch.zeros(num_classes, num_classes, device=z.device, dtype=torch.int64)
+    pred = torch.empty(B, H, W, device=z.device, dtype=torch.int64)
+    lib.call("kd_argmax_confusion", P(z), P(target.contiguous()), int(ignore_index), P(out), P(pred), B, NC, H * W, stream())
+    return out, pred

@@ -1,0 +1,167 @@
+"""Thin tensor-level wrappers over the C ABI (include/kd_hip.h).
+
+Everything here is pointer plumbing: take torch tensors that already live in HBM, hand raw
+device pointers + sizes + the current HIP stream to libkd_hip.so.  No arithmetic happens in Python.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .lib import KDError, lib, require_gpu_tensor
+
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+_ws = {}
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """One grow-only scratch buffer per device.  All kernels are stream-ordered, and every C entry
+    point consumes its workspace before it returns control to the stream, so sharing is safe."""
+    key = (device.type, device.index)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def P(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def ld(t: torch.Tensor) -> int:
+    """row stride (floats) of a 2-D [M, C] view with unit inner stride"""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise KDError(f"expected a [M, C] view with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0)
+
+
+class BNC:
+    """Per-channel BatchNorm coefficients of one layer for one forward pass."""
+    __slots__ = ("buf", "mean", "invstd", "scale", "shift")
+
+    def __init__(self, C: int, device, buf: Optional[torch.Tensor] = None):
+        self.buf = torch.empty(4, C, device=device, dtype=torch.float32) if buf is None else buf
+        self.mean, self.invstd, self.scale, self.shift = self.buf[0], self.buf[1], self.buf[2], self.buf[3]
+
+
+class Operand:
+    """A possibly-deferred NHWC activation: value = act(raw*sc+sh), or raw itself when bnc is None.
+    raw is a [M, C] view (row stride = ld); geom = (B, H, W) with M = B*H*W."""
+    __slots__ = ("raw", "bnc", "act", "geom")
+
+    def __init__(self, raw: torch.Tensor, geom, bnc: Optional[BNC] = None, act: int = ACT_NONE):
+        self.raw, self.bnc, self.act, self.geom = raw, bnc, act, geom
+
+    @property
+    def M(self):
+        return self.raw.shape[0]
+
+    @property
+    def C(self):
+        return self.raw.shape[1]
+
+    @property
+    def sc(self):
+        return None if self.bnc is None else self.bnc.scale
+
+    @property
+    def sh(self):
+        return None if self.bnc is None else self.bnc.shift
+
+
+# ---------------------------------------------------------------------------------------------
+def nhwc_view(x: torch.Tensor) -> Tuple[torch.Tensor, tuple]:
+    """NCHW-shaped tensor -> ([M, C] NHWC matrix view, (B, H, W)).  Channels-last tensors are used
+    in place; anything else is re-laid-out once by the allocator's copy (layout plumbing)."""
+    require_gpu_tensor(x, "kdrt.ops")
+    if x.dtype != torch.float32:
+        raise KDError(f"fp32 tensors expected, got {x.dtype}")
+    B, C, H, W = x.shape
+    xp = x.permute(0, 2, 3, 1)
+    if not xp.is_contiguous():
+        xp = xp.contiguous()
+    return xp.reshape(B * H * W, C), (B, H, W)
+
+
+def nchw_from_matrix(m: torch.Tensor, geom) -> torch.Tensor:
+    """[M, C] NHWC matrix -> NCHW-shaped (channels-last strided) view, no copy."""
+    B, H, W = geom
+    return m.view(B, H, W, m.shape[1]).permute(0, 3, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+def bn_finalize_train(partial, rows, C, count, bn, bnc: BNC, update_running=True, pstride=None):
+    lib.call("kd_bn_finalize_train", P(partial), rows, C, pstride or C, count, P(bn.weight), P(bn.bias), BN_EPS,
+             bn.momentum if bn.momentum is not None else BN_MOMENTUM,
+             P(bn.running_mean) if update_running else None, P(bn.running_var) if update_running else None,
+             P(bn.num_batches_tracked) if update_running else None,
+             P(bnc.mean), P(bnc.invstd), P(bnc.scale), P(bnc.shift), stream())
+
+
+def bn_eval_coeffs(bn, bnc: BNC):
+    C = bn.running_mean.numel()
+    lib.call("kd_bn_eval_coeffs", P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var), bn.eps, C,
+             P(bnc.mean), P(bnc.invstd), P(bnc.scale), P(bnc.shift), stream())
+
+
+def pw_gemm(A, W, C_out, *, M, K, N, A2=None, pro=0, pro_act=0, p=(None,) * 5, bias=None, addend=None, epi=0,
+            X=None, esc=None, esh=None, emean=None, einv=None, epi_act=0, partial=None):
+    lib.call("kd_pwconv_gemm", P(A), ld(A), P(A2), ld(A2) if A2 is not None else 0, pro, pro_act,
+             P(p[0]), P(p[1]), P(p[2]), P(p[3]), P(p[4]), P(W), P(bias), P(C_out), ld(C_out),
+             P(addend), ld(addend) if addend is not None else 0, epi, P(X), ld(X) if X is not None else 0,
+             P(esc), P(esh), P(emean), P(einv), epi_act, P(partial), M, K, N, stream())
+
+
+def pw_wgrad(D, A, dW, *, M, N, K, X=None, d_mode=0, d_act=0, al=None, be=None, ga=None, msc=None, msh=None,
+             a_mode=0, a_act=0, asc=None, ash=None):
+    nbytes = lib.kd_pwconv_wgrad_ws_bytes(M, N, K)
+    ws = workspace(nbytes, D.device)
+    lib.call("kd_pwconv_wgrad", P(D), ld(D), P(X), ld(X) if X is not None else 0, d_mode, d_act, P(al), P(be), P(ga),
+             P(msc), P(msh), P(A), ld(A), a_mode, a_act, P(asc), P(ash), P(dW), M, N, K, P(ws), nbytes, stream())
+
+
+def transpose(w2d: torch.Tensor) -> torch.Tensor:
+    R, Cc = w2d.shape
+    out = torch.empty(Cc, R, device=w2d.device, dtype=torch.float32)
+    lib.call("kd_transpose", P(w2d), P(out), R, Cc, stream())
+    return out
+
+
+def bn_act_apply(x, sc, sh, act, out, res=None):
+    M, C = x.shape
+    lib.call("kd_bn_act_apply", P(x), ld(x), P(sc), P(sh), act, P(res), ld(res) if res is not None else 0, P(out),
+             ld(out), M, C, stream())
+    return out
+
+
+def materialize(op: Operand, res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    if out is None:
+        out = torch.empty(op.M, op.C, device=op.raw.device, dtype=torch.float32)
+    return bn_act_apply(op.raw, op.sc, op.sh, op.act, out, res)
+
+
+def bn_bwd_reduce(D, op: Operand):
+    """(sum G, sum G*xhat) partial slab for G = D * act'(.) over the deferred operand `op`."""
+    M, C = op.M, op.C
+    rows = lib.kd_rowwise_stat_rows(M, C)
+    partial = torch.empty(rows * 2 * C, device=D.device, dtype=torch.float32)
+    lib.call("kd_bn_bwd_reduce", P(D), ld(D), P(op.raw), ld(op.raw), P(op.sc), P(op.sh), op.act,
+             P(op.bnc.mean), P(op.bnc.invstd), P(partial), M, C, stream())
+    return partial, rows
+
+
+def bn_bwd_finalize(partial, rows, C, count, gamma, bnc: BNC, training: bool, want_dbias=False, pstride=None):
+    """-> (dgamma, dbeta, abg[3,C], dbias|None)"""
+    dev = partial.device
+    out = torch.empty(6, C, device=dev, dtype=torch.float32)
+    lib.call("kd_bn_bwd_finalize", P(partial), rows, C, pstride or C, count, P(gamma), P(bnc.mean), P(bnc.invstd), int(training),
+             P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(out[4]), P(out[5]) if want_dbias else None, stream())
+    return out[0], out[1], out[2:5], (out[5] if want_dbias else None)

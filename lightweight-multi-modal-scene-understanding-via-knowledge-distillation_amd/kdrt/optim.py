@@ -1,0 +1,84 @@
+"""Fused AdamW over one flat parameter buffer (torch.optim.AdamW math, trainer.py:56).
+
+All parameters are re-homed as views of one contiguous fp32 buffer, gradients likewise, so the
+optimiser step is ONE kernel launch and the DDP all-reduce works on contiguous bucket slices.
+`state_dict()` / `load_state_dict()` keep torch.optim.AdamW's layout (per-parameter `step`,
+`exp_avg`, `exp_avg_sq`) so reference checkpoints (`optimizer_state`, trainer.py:116-142) load.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+
+from . import ops
+from .lib import lib
+from .ops import P, stream
+
+
+class FlatParams:
+    """Re-homes `params` (in the given order) into one flat buffer; p.data and p.grad become views."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        self.offsets = [0]
+        for s in sizes:
+            self.offsets.append(self.offsets[-1] + ((s + 3) // 4) * 4)      # keep 16-byte alignment per tensor
+        self.numel = self.offsets[-1]
+        self.data = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.data[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.data[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):      # re-attach views if something replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.flat = FlatParams(params)
+        self.exp_avg = torch.zeros_like(self.flat.data)
+        self.exp_avg_sq = torch.zeros_like(self.flat.data)
+        self._step = 0
+        self.grad_scale = 1.0            # set to 1/world_size by the DDP wrapper (sum all-reduce)
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            n = p.numel()
+            self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.exp_avg[o:o + n].view(p.shape),
+                             "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape)}
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self._step += 1
+        lib.call("kd_adamw_step", P(self.flat.data), P(self.flat.grad), P(self.exp_avg), P(self.exp_avg_sq), self.flat.numel,
+                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                 self._step, float(self.grad_scale), stream())
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._step))
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # re-home the loaded moments into the flat buffers
+        steps = []
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            st = self.state[p]
+            n = p.numel()
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            st["exp_avg"] = self.exp_avg[o:o + n].view(p.shape)
+            st["exp_avg_sq"] = self.exp_avg_sq[o:o + n].view(p.shape)
+            steps.append(int(float(st["step"])))
+        self._step = max(steps) if steps else 0

@@ -1,0 +1,583 @@
+"""Conv+BN(+act) "units" and the autograd Functions that chain them.
+
+A unit is one convolution followed by BatchNorm (and an activation id).  Its forward writes the
+RAW conv output once and leaves BN+activation *deferred*: the next kernel applies them while
+loading (ops.Operand).  Its backward consumes the gradient of its activated output -- either
+unmasked ("D") or already multiplied by act' with the BN-backward sums attached ("G") -- and
+returns parameter gradients plus the gradient for its own input in the same protocol.
+
+Which reference module each Function stands in for is noted on the Function.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .lib import KDError, lib
+from .ops import ACT_NONE, ACT_RELU, ACT_RELU6, BNC, Operand, P, ld, stream
+
+
+class UnitSpec:
+    """kind: 'pw' (1x1 conv / Conv1d k=1), 'dw' (depthwise 3x3), 'stem' (3x3 s2 dense), 'l0' (LiDAR 4->C)."""
+
+    def __init__(self, kind: str, conv, bn, act: int):
+        self.kind, self.conv, self.bn, self.act = kind, conv, bn, act
+        self.stride = conv.stride[0] if kind in ("dw", "stem") else 1
+        self.has_bias = conv.bias is not None
+
+    def params(self) -> List[torch.Tensor]:
+        p = [self.conv.weight]
+        if self.has_bias:
+            p.append(self.conv.bias)
+        return p + [self.bn.weight, self.bn.bias]
+
+
+class _Rec:
+    __slots__ = ("spec", "inp", "y", "bnc", "training", "out_geom", "w", "b", "gamma", "image")
+
+
+def _coeffs(spec: UnitSpec, partial, rows, C, count, training, bnc=None, device=None):
+    bnc = bnc if bnc is not None else BNC(C, device)
+    if training:
+        ops.bn_finalize_train(partial, rows, C, count, spec.bn, bnc)
+    else:
+        ops.bn_eval_coeffs(spec.bn, bnc)
+    return bnc
+
+
+def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] = None, bnc: Optional[BNC] = None):
+    """inp: Operand (or, for 'stem', the NCHW image tensor; for 'l0', the [P,4] points).
+    Returns (output Operand, record for backward)."""
+    rec = _Rec()
+    rec.spec, rec.inp, rec.training = spec, inp, training
+    w, b = spec.conv.weight, spec.conv.bias
+    rec.w, rec.b, rec.gamma = w, b, spec.bn.weight
+    rec.image = None
+    kind = spec.kind
+    if kind == "pw":
+        N, K = w.shape[0], w.shape[1]
+        M = inp.M
+        if inp.C != K:
+            raise KDError(f"pointwise conv expects {K} input channels, got {inp.C}")
+        dev = inp.raw.device
+        if y is None:
+            y = torch.empty(M, N, device=dev, dtype=torch.float32)
+        partial, rows = None, 0
+        if training:
+            rows = lib.kd_pwconv_stat_rows(M)
+            partial = torch.empty(rows * 2 * N, device=dev, dtype=torch.float32)
+        ops.pw_gemm(inp.raw, w, y, M=M, K=K, N=N, pro=1 if inp.bnc is not None else 0, pro_act=inp.act,
+                    p=(inp.sc, inp.sh, None, None, None), bias=b, epi=1 if training else 0, partial=partial)
+        rec.out_geom = inp.geom
+        rec.bnc = _coeffs(spec, partial, rows, N, M, training, bnc, dev)
+    elif kind == "dw":
+        B, H, W = inp.geom
+        C = inp.C
+        if ld(inp.raw) != C:
+            raise KDError("depthwise conv needs a dense NHWC input")
+        s = spec.stride
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        dev = inp.raw.device
+        y = torch.empty(B * Ho * Wo, C, device=dev, dtype=torch.float32)
+        partial, rows = None, 0
+        if training:
+            rows = lib.kd_dwconv_stat_rows(B * Ho * Wo, C)
+            partial = torch.empty(rows * 2 * C, device=dev, dtype=torch.float32)
+        lib.call("kd_dwconv3x3_fwd", P(inp.raw), P(inp.sc), P(inp.sh), inp.act, P(w), P(y), P(partial), B, H, W, C, s,
+                 stream())
+        rec.out_geom = (B, Ho, Wo)
+        rec.bnc = _coeffs(spec, partial, rows, C, B * Ho * Wo, training, bnc, dev)
+    elif kind == "stem":
+        img = inp if inp.is_contiguous() else inp.contiguous()
+        ops.require_gpu_tensor(img, "stem conv")
+        B, Cin, H, W = img.shape
+        Cout = w.shape[0]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        dev = img.device
+        y = torch.empty(B * Ho * Wo, Cout, device=dev, dtype=torch.float32)
+        partial, rows = None, 0
+        if training:
+            rows = lib.kd_stem_stat_rows(B * Ho * Wo)
+            partial = torch.empty(rows * 2 * Cout, device=dev, dtype=torch.float32)
+        lib.call("kd_stem_conv_fwd", P(img), P(w), P(y), P(partial), B, Cin, H, W, Cout, stream())
+        rec.image = img
+        rec.out_geom = (B, Ho, Wo)
+        rec.bnc = _coeffs(spec, partial, rows, Cout, B * Ho * Wo, training, bnc, dev)
+    elif kind == "l0":
+        pts = inp                                    # [P, 4] contiguous
+        Pn, C = pts.shape[0], w.shape[0]
+        dev = pts.device
+        y = torch.empty(Pn, C, device=dev, dtype=torch.float32)
+        partial, rows = None, 0
+        if training:
+            rows = lib.kd_rowwise_stat_rows(Pn, C)
+            partial = torch.empty(rows * 2 * C, device=dev, dtype=torch.float32)
+        lib.call("kd_lidar_l0_fwd", P(pts), P(w), P(b), P(y), P(partial), Pn, C, stream())
+        rec.out_geom = (Pn, 1, 1)
+        rec.bnc = _coeffs(spec, partial, rows, C, Pn, training, bnc, dev)
+    else:
+        raise KDError(f"unknown unit kind {kind}")
+    rec.y = y
+    return Operand(y, rec.out_geom, rec.bnc, spec.act), rec
+
+
+def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[torch.Tensor] = None):
+    """g: ("D", dA) unmasked gradient w.r.t. the activated output, or ("G", G, partial, rows[, pstride])
+    already masked with BN-backward sums.  Returns (param grads aligned with spec.params(), g_in) where
+    g_in is ("G", ...) if the input was deferred, a plain [M, C] tensor if it was materialised, or None."""
+    spec = rec.spec
+    y, bnc = rec.y, rec.bnc
+    M, C = y.shape
+    out_op = Operand(y, rec.out_geom, bnc, spec.act)
+    pstride = None
+    if g[0] == "D":
+        t = g[1]
+        partial, rows = ops.bn_bwd_reduce(t, out_op)
+        msc, msh, mact = bnc.scale, bnc.shift, spec.act
+        if mact == ACT_NONE:
+            msc = msh = None
+    else:
+        t, partial, rows = g[1], g[2], g[3]
+        pstride = g[4] if len(g) > 4 else None
+        msc, msh, mact = None, None, ACT_NONE
+    dgamma, dbeta, abg, dbias = ops.bn_bwd_finalize(partial, rows, C, M, rec.gamma, bnc, rec.training,
+                                                    want_dbias=spec.has_bias and spec.kind != "l0", pstride=pstride)
+    al, be, ga = abg[0], abg[1], abg[2]
+    dev = y.device
+    kind = spec.kind
+    g_in = None
+    if kind == "pw":
+        inp = rec.inp
+        N, K = C, inp.C
+        dW = torch.empty_like(rec.w)
+        ops.pw_wgrad(t, inp.raw, dW, M=M, N=N, K=K, X=y, d_mode=2, d_act=mact, al=al, be=be, ga=ga, msc=msc, msh=msh,
+                     a_mode=1 if inp.bnc is not None else 0, a_act=inp.act, asc=inp.sc, ash=inp.sh)
+        if need_input_grad:
+            Wt = ops.transpose(rec.w.view(N, K))
+            if inp.bnc is not None:
+                gin = torch.empty(M, K, device=dev, dtype=torch.float32)
+                rows_in = lib.kd_pwconv_stat_rows(M)
+                part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
+                ops.pw_gemm(t, Wt, gin, M=M, K=N, N=K, A2=y, pro=2, pro_act=mact, p=(al, be, ga, msc, msh),
+                            addend=addend, epi=2, X=inp.raw, esc=inp.sc, esh=inp.sh, emean=inp.bnc.mean,
+                            einv=inp.bnc.invstd, epi_act=inp.act, partial=part_in)
+                g_in = ("G", gin, part_in, rows_in)
+            else:
+                dx = torch.empty(M, K, device=dev, dtype=torch.float32)
+                ops.pw_gemm(t, Wt, dx, M=M, K=N, N=K, A2=y, pro=2, pro_act=mact, p=(al, be, ga, msc, msh),
+                            addend=addend, epi=0)
+                g_in = dx
+        grads = [dW]
+    elif kind == "dw":
+        inp = rec.inp
+        B, H, W = inp.geom
+        s = spec.stride
+        npix_out = M
+        dW = torch.empty_like(rec.w)
+        nbytes = lib.kd_dwconv_bwd_ws_bytes(npix_out, C)
+        ws = ops.workspace(nbytes, dev)
+        gx = part_in = None
+        rows_in = 0
+        deferred = inp.bnc is not None
+        if need_input_grad:
+            gx = torch.empty(inp.M, C, device=dev, dtype=torch.float32)
+            if deferred:
+                rows_in = lib.kd_dwconv_bwd_stat_rows(inp.M, C)
+                part_in = torch.empty(rows_in * 2 * C, device=dev, dtype=torch.float32)
+        lib.call("kd_dwconv3x3_bwd", P(t), P(y), P(al), P(be), P(ga), P(msc), P(msh), mact, P(inp.raw), P(inp.sc),
+                 P(inp.sh), inp.act, P(inp.bnc.mean) if deferred else None, P(inp.bnc.invstd) if deferred else None,
+                 P(rec.w), P(gx), P(part_in), P(dW), B, H, W, C, s, P(ws), nbytes, stream())
+        if need_input_grad:
+            if deferred:
+                if addend is not None:
+                    raise KDError("addend on a deferred depthwise input is not supported")
+                g_in = ("G", gx, part_in, rows_in)
+            else:
+                if addend is not None:
+                    ops.bn_act_apply(gx, None, None, ACT_NONE, gx, res=addend)
+                g_in = gx
+        grads = [dW]
+    elif kind == "stem":
+        img = rec.image
+        B, Cin, H, W = img.shape
+        Kp = 32
+        col = torch.empty(M, Kp, device=dev, dtype=torch.float32)
+        lib.call("kd_stem_im2col", P(img), P(col), B, Cin, H, W, Kp, stream())
+        dWp = torch.empty(C, Kp, device=dev, dtype=torch.float32)
+        ops.pw_wgrad(t, col, dWp, M=M, N=C, K=Kp, X=y, d_mode=2, d_act=mact, al=al, be=be, ga=ga, msc=msc, msh=msh)
+        grads = [dWp[:, : Cin * 9].reshape(rec.w.shape)]
+    elif kind == "l0":
+        if g[0] != "G":
+            raise KDError("LiDAR layer-0 backward expects a masked gradient")
+        pts = rec.inp
+        nbytes = lib.kd_lidar_l0_bwd_ws_bytes(M, C)
+        ws = ops.workspace(nbytes, dev)
+        dwb = torch.empty(C * 5, device=dev, dtype=torch.float32)
+        lib.call("kd_lidar_l0_bwd", P(t), P(y), P(al), P(be), P(ga), P(pts), P(dwb), M, C, P(ws), nbytes, stream())
+        grads = [dwb[: C * 4].view(rec.w.shape), dwb[C * 4:]]
+    if spec.has_bias and kind != "l0":
+        grads.append(dbias)
+    grads += [dgamma, dbeta]
+    return grads, g_in
+
+
+def chain_backward(recs: Sequence[_Rec], g, need_input_grad=True, first_addend=None):
+    """Walk a linear chain of units in reverse.  Returns (param grads in forward order, input grad)."""
+    all_grads: List[torch.Tensor] = []
+    for i in range(len(recs) - 1, -1, -1):
+        first = i == 0
+        pg, g = unit_backward(recs[i], g, need_input_grad=(need_input_grad or not first),
+                              addend=first_addend if first else None)
+        all_grads = pg + all_grads
+    return all_grads, g
+
+
+def _params_of(units: Sequence[UnitSpec]) -> List[torch.Tensor]:
+    out = []
+    for u in units:
+        out += u.params()
+    return out
+
+
+# =================================================================================================
+class ChainFn(torch.autograd.Function):
+    """x -> unit_1 -> ... -> unit_n -> materialise (+ x if residual).
+    Stands in for: TwinLiteEncoder.stem (camera_encoder.py:63-67), InvertedResidual.forward (:46-51),
+    Conv1x1.forward (fusion_module.py:16-17), DWSeparableConv.forward (:33-34)."""
+
+    @staticmethod
+    def forward(ctx, x, units, residual, training, *params):
+        recs = []
+        if units[0].kind == "stem":
+            ops.require_gpu_tensor(x, "TwinLiteEncoder")
+            cur, xm = x, None
+        else:
+            xm, geom = ops.nhwc_view(x)
+            cur = Operand(xm, geom)
+        for u in units:
+            cur, rec = unit_forward(u, cur, training)
+            recs.append(rec)
+        out = ops.materialize(cur, res=xm if residual else None)
+        ctx.recs, ctx.residual, ctx.geom = recs, residual, cur.geom
+        return ops.nchw_from_matrix(out, cur.geom)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dm, _ = ops.nhwc_view(dout)
+        need = ctx.needs_input_grad[0] and ctx.recs[0].spec.kind != "stem"
+        grads, g_in = chain_backward(ctx.recs, ("D", dm), need_input_grad=need,
+                                     first_addend=dm if ctx.residual else None)
+        dx = None
+        if need:
+            dx = ops.nchw_from_matrix(g_in, ctx.recs[0].inp.geom)
+        return (dx, None, None, None, *grads)
+
+
+def run_chain(x, units: Sequence[UnitSpec], residual: bool, training: bool):
+    return ChainFn.apply(x, list(units), residual, training, *_params_of(units))
+
+
+# =================================================================================================
+class FPNFn(torch.autograd.Function):
+    """CameraFPNLite.forward (fusion_module.py:51-64): laterals (Conv1x1) -> bilinear resize to the
+    largest stage -> running sum -> DWSeparableConv post block."""
+
+    @staticmethod
+    def forward(ctx, n_stage, laterals, post_units, training, *tensors):
+        feats = tensors[:n_stage]
+        lat_ops, lat_recs, in_geoms = [], [], []
+        for f, u in zip(feats, laterals):
+            xm, geom = ops.nhwc_view(f)
+            op, rec = unit_forward(u, Operand(xm, geom), training)
+            lat_ops.append(op); lat_recs.append(rec); in_geoms.append(geom)
+        B = in_geoms[0][0]
+        Ho, Wo = max(((g[1], g[2]) for g in in_geoms), key=lambda hw: hw[0] * hw[1])
+        Ct = lat_ops[0].C
+        dev = lat_ops[0].raw.device
+        fused = torch.empty(B * Ho * Wo, Ct, device=dev, dtype=torch.float32)
+        for i, op in enumerate(lat_ops):
+            _, Hi, Wi = op.geom
+            lib.call("kd_bilinear_accum_fwd", P(op.raw), P(op.sc), P(op.sh), op.act, P(fused), int(i > 0), B, Hi, Wi,
+                     Ho, Wo, Ct, stream())
+        cur = Operand(fused, (B, Ho, Wo))
+        post_recs = []
+        for u in post_units:
+            cur, rec = unit_forward(u, cur, training)
+            post_recs.append(rec)
+        out = ops.materialize(cur)
+        ctx.lat_ops, ctx.lat_recs, ctx.post_recs, ctx.geom, ctx.n_stage = lat_ops, lat_recs, post_recs, (B, Ho, Wo), n_stage
+        return ops.nchw_from_matrix(out, cur.geom)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dm, _ = ops.nhwc_view(dout)
+        post_grads, dfused = chain_backward(ctx.post_recs, ("D", dm), need_input_grad=True)
+        B, Ho, Wo = ctx.geom
+        feat_grads, lat_grads = [], []
+        for i, (op, rec) in enumerate(zip(ctx.lat_ops, ctx.lat_recs)):
+            _, Hi, Wi = op.geom
+            C = op.C
+            rows = lib.kd_rowwise_stat_rows(op.M, C)
+            gin = torch.empty(op.M, C, device=dm.device, dtype=torch.float32)
+            partial = torch.empty(rows * 2 * C, device=dm.device, dtype=torch.float32)
+            lib.call("kd_bilinear_bwd", P(dfused), P(op.raw), P(op.sc), P(op.sh), op.act, P(op.bnc.mean),
+                     P(op.bnc.invstd), P(gin), P(partial), B, Hi, Wi, Ho, Wo, C, stream())
+            need = ctx.needs_input_grad[4 + i]
+            pg, gx = unit_backward(rec, ("G", gin, partial, rows), need_input_grad=need)
+            lat_grads += pg
+            feat_grads.append(ops.nchw_from_matrix(gx, rec.inp.geom) if need else None)
+        return (None, None, None, None, *feat_grads, *lat_grads, *post_grads)
+
+
+def run_fpn(feats: Sequence[torch.Tensor], laterals: Sequence[UnitSpec], post_units: Sequence[UnitSpec], training):
+    return FPNFn.apply(len(feats), list(laterals), list(post_units), training, *feats, *_params_of(laterals),
+                       *_params_of(post_units))
+
+
+# =================================================================================================
+def _proj_pair(cam, lid, u_cam: UnitSpec, u_lid: UnitSpec, training):
+    """Run the two Conv1x1 projections into ONE [M, Cc+Cl] raw buffer (the concat is free) with one
+    combined coefficient table."""
+    cm, geom = ops.nhwc_view(cam)
+    lm, geom_l = ops.nhwc_view(lid)
+    if geom != geom_l:
+        raise KDError(f"camera / LiDAR feature maps differ in size: {geom} vs {geom_l} (resize path not built)")
+    Cc, Cl = u_cam.conv.weight.shape[0], u_lid.conv.weight.shape[0]
+    dev = cm.device
+    cat = torch.empty(cm.shape[0], Cc + Cl, device=dev, dtype=torch.float32)
+    comb = BNC(Cc + Cl, dev)
+    op_c, rec_c = unit_forward(u_cam, Operand(cm, geom), training, y=cat[:, :Cc], bnc=BNC(Cc, dev, comb.buf[:, :Cc]))
+    op_l, rec_l = unit_forward(u_lid, Operand(lm, geom), training, y=cat[:, Cc:], bnc=BNC(Cl, dev, comb.buf[:, Cc:]))
+    return cat, comb, (op_c, rec_c), (op_l, rec_l), geom
+
+
+def _proj_pair_backward(ctx, gcat, partial, rows, Cc, Cl, need_cam, need_lid):
+    """Split the masked gradient of the concat buffer between the two projection units."""
+    tot = Cc + Cl
+    g_c = ("G", gcat[:, :Cc], partial, rows, tot)
+    g_l = ("G", gcat[:, Cc:], partial[Cc:], rows, tot)
+    pg_c, dcam = unit_backward(ctx.rec_c, g_c, need_input_grad=need_cam)
+    pg_l, dlid = unit_backward(ctx.rec_l, g_l, need_input_grad=need_lid)
+    dcam = ops.nchw_from_matrix(dcam, ctx.rec_c.inp.geom) if need_cam else None
+    dlid = ops.nchw_from_matrix(dlid, ctx.rec_l.inp.geom) if need_lid else None
+    return dcam, dlid, pg_c, pg_l
+
+
+class ConcatFuseFn(torch.autograd.Function):
+    """The concat branch of CompleteSegmentationModel.forward (fusion_module.py:242-246):
+    camera_proj / lidar_proj -> cat -> fuse (dw3x3+BN+ReLU, pw+BN+ReLU).
+    Returns (fused, pre_fusion); pre_fusion is a by-product for `return_intermediates` and is
+    marked non-differentiable."""
+
+    @staticmethod
+    def forward(ctx, cam, lid, u_cam, u_lid, fuse_units, training, *params):
+        cat, comb, (op_c, rec_c), (op_l, rec_l), geom = _proj_pair(cam, lid, u_cam, u_lid, training)
+        cur = Operand(cat, geom, comb, ACT_RELU)
+        pre = ops.materialize(cur)
+        recs = []
+        for u in fuse_units:
+            cur, rec = unit_forward(u, cur, training)
+            recs.append(rec)
+        out = ops.materialize(cur)
+        ctx.rec_c, ctx.rec_l, ctx.recs = rec_c, rec_l, recs
+        ctx.Cc, ctx.Cl = op_c.C, op_l.C
+        pre_t = ops.nchw_from_matrix(pre, geom)
+        ctx.mark_non_differentiable(pre_t)
+        return ops.nchw_from_matrix(out, geom), pre_t
+
+    @staticmethod
+    def backward(ctx, dout, _dpre):
+        dm, _ = ops.nhwc_view(dout)
+        fuse_grads, g = chain_backward(ctx.recs, ("D", dm), need_input_grad=True)
+        _, gcat, partial, rows = g
+        dcam, dlid, pg_c, pg_l = _proj_pair_backward(ctx, gcat, partial, rows, ctx.Cc, ctx.Cl,
+                                                     ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return (dcam, dlid, None, None, None, None, *pg_c, *pg_l, *fuse_grads)
+
+
+def run_concat_fuse(cam, lid, u_cam, u_lid, fuse_units, training):
+    return ConcatFuseFn.apply(cam, lid, u_cam, u_lid, list(fuse_units), training, *u_cam.params(), *u_lid.params(),
+                              *_params_of(fuse_units))
+
+
+class WeightedFuseFn(torch.autograd.Function):
+    """The weighted branch (fusion_module.py:248-253 with WeightedFusion.attention :115-120):
+    cam_proj / lidar_proj -> cat -> conv1x1(2C->C, bias)+ReLU -> conv1x1(C->2, bias) -> softmax ->
+    cam_proj*w0 + lidar_proj*w1."""
+
+    @staticmethod
+    def forward(ctx, cam, lid, u_cam, u_lid, training, w1, b1, w2, b2, *params):
+        cat, comb, (op_c, rec_c), (op_l, rec_l), geom = _proj_pair(cam, lid, u_cam, u_lid, training)
+        M, C = cat.shape[0], op_c.C
+        if op_l.C != C or w1.shape[0] != C or w1.shape[1] != 2 * C or w2.shape[0] != 2:
+            raise KDError("weighted fusion expects equal projection widths and a 2-way attention head")
+        dev = cat.device
+        hraw = torch.empty(M, C, device=dev, dtype=torch.float32)
+        ops.pw_gemm(cat, w1, hraw, M=M, K=2 * C, N=C, pro=1, pro_act=ACT_RELU, p=(comb.scale, comb.shift, None, None, None),
+                    bias=b1, epi=0)
+        out = torch.empty(M, C, device=dev, dtype=torch.float32)
+        wts = torch.empty(M, 2, device=dev, dtype=torch.float32)
+        lib.call("kd_weighted_fuse_fwd", P(cat), P(comb.scale), P(comb.shift), P(hraw), P(w2), P(b2), P(out), P(wts), M, C,
+                 stream())
+        ctx.rec_c, ctx.rec_l, ctx.cat, ctx.comb, ctx.hraw, ctx.wts = rec_c, rec_l, cat, comb, hraw, wts
+        ctx.w1, ctx.w2, ctx.C, ctx.geom = w1, w2, C, geom
+        return ops.nchw_from_matrix(out, geom)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dm, _ = ops.nhwc_view(dout)
+        C, cat, comb = ctx.C, ctx.cat, ctx.comb
+        M = cat.shape[0]
+        dev = cat.device
+        dcat = torch.empty(M, 2 * C, device=dev, dtype=torch.float32)
+        gh = torch.empty(M, C, device=dev, dtype=torch.float32)
+        dpar = torch.empty(3 * C + 4, device=dev, dtype=torch.float32)
+        nbytes = lib.kd_weighted_fuse_bwd_ws_bytes(M, C)
+        ws = ops.workspace(nbytes, dev)
+        lib.call("kd_weighted_fuse_bwd", P(dm), P(cat), P(comb.scale), P(comb.shift), P(ctx.hraw), P(ctx.w2), P(ctx.wts),
+                 P(dcat), P(gh), P(dpar), M, C, P(ws), nbytes, stream())
+        dw2 = dpar[: 2 * C].view(ctx.w2.shape)
+        db1 = dpar[2 * C: 3 * C]
+        db2 = dpar[3 * C: 3 * C + 2]
+        dw1 = torch.empty_like(ctx.w1)
+        ops.pw_wgrad(gh, cat, dw1, M=M, N=C, K=2 * C, d_mode=0, a_mode=1, a_act=ACT_RELU, asc=comb.scale, ash=comb.shift)
+        w1t = ops.transpose(ctx.w1.view(C, 2 * C))
+        rows = lib.kd_pwconv_stat_rows(M)
+        partial = torch.empty(rows * 2 * 2 * C, device=dev, dtype=torch.float32)
+        gcat = torch.empty(M, 2 * C, device=dev, dtype=torch.float32)
+        ops.pw_gemm(gh, w1t, gcat, M=M, K=C, N=2 * C, pro=0, addend=dcat, epi=2, X=cat, esc=comb.scale, esh=comb.shift,
+                    emean=comb.mean, einv=comb.invstd, epi_act=ACT_RELU, partial=partial)
+        dcam, dlid, pg_c, pg_l = _proj_pair_backward(ctx, gcat, partial, rows, C, C, ctx.needs_input_grad[0],
+                                                     ctx.needs_input_grad[1])
+        return (dcam, dlid, None, None, None, dw1, db1, dw2, db2, *pg_c, *pg_l)
+
+
+def run_weighted_fuse(cam, lid, u_cam, u_lid, att0, att2, training):
+    return WeightedFuseFn.apply(cam, lid, u_cam, u_lid, training, att0.weight, att0.bias, att2.weight, att2.bias,
+                                *u_cam.params(), *u_lid.params())
+
+
+class MinimalFuseFn(torch.autograd.Function):
+    """The minimal branch (fusion_module.py:248-249,255): cam_proj(cam) + lidar_proj(lidar)."""
+
+    @staticmethod
+    def forward(ctx, cam, lid, u_cam, u_lid, training, *params):
+        cm, geom = ops.nhwc_view(cam)
+        lm, geom_l = ops.nhwc_view(lid)
+        if geom != geom_l:
+            raise KDError("camera / LiDAR feature maps differ in size (resize path not built)")
+        op_c, rec_c = unit_forward(u_cam, Operand(cm, geom), training)
+        op_l, rec_l = unit_forward(u_lid, Operand(lm, geom), training)
+        t = ops.materialize(op_c)
+        out = ops.materialize(op_l, res=t, out=t)
+        ctx.rec_c, ctx.rec_l = rec_c, rec_l
+        return ops.nchw_from_matrix(out, geom)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dm, _ = ops.nhwc_view(dout)
+        pg_c, dcam = unit_backward(ctx.rec_c, ("D", dm), need_input_grad=ctx.needs_input_grad[0])
+        pg_l, dlid = unit_backward(ctx.rec_l, ("D", dm), need_input_grad=ctx.needs_input_grad[1])
+        dcam = ops.nchw_from_matrix(dcam, ctx.rec_c.inp.geom) if dcam is not None else None
+        dlid = ops.nchw_from_matrix(dlid, ctx.rec_l.inp.geom) if dlid is not None else None
+        return (dcam, dlid, None, None, None, *pg_c, *pg_l)
+
+
+def run_minimal_fuse(cam, lid, u_cam, u_lid, training):
+    return MinimalFuseFn.apply(cam, lid, u_cam, u_lid, training, *u_cam.params(), *u_lid.params())
+
+
+# =================================================================================================
+class SameHeadFn(torch.autograd.Function):
+    """SameResolutionSegmentationHead.forward (fusion_module.py:172-173): two DWSeparableConv blocks
+    then the 1x1 classifier (bias) writing NCHW logits."""
+
+    @staticmethod
+    def forward(ctx, x, units, training, wc, bc, *params):
+        xm, geom = ops.nhwc_view(x)
+        cur = Operand(xm, geom)
+        recs = []
+        for u in units:
+            cur, rec = unit_forward(u, cur, training)
+            recs.append(rec)
+        B, H, W = cur.geom
+        NC, Cin = wc.shape[0], wc.shape[1]
+        logits = torch.empty(B, NC, H, W, device=xm.device, dtype=torch.float32)
+        lib.call("kd_cls_conv_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(wc), P(bc), P(logits), cur.M, H * W, Cin,
+                 NC, stream())
+        ctx.recs, ctx.last, ctx.wc = recs, cur, wc
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlog):
+        dlog = dlog.contiguous()
+        cur, wc = ctx.last, ctx.wc
+        B, H, W = cur.geom
+        NC, Cin = wc.shape[0], wc.shape[1]
+        M = cur.M
+        dev = dlog.device
+        gx = torch.empty(M, Cin, device=dev, dtype=torch.float32)
+        rows = lib.kd_cls_conv_bwd_stat_rows(M, Cin)
+        partial = torch.empty(rows * 2 * Cin, device=dev, dtype=torch.float32)
+        dwb = torch.empty(NC * Cin + 4, device=dev, dtype=torch.float32)
+        nbytes = lib.kd_cls_conv_bwd_ws_bytes(M, Cin, NC)
+        ws = ops.workspace(nbytes, dev)
+        lib.call("kd_cls_conv_bwd", P(dlog), P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(cur.bnc.mean), P(cur.bnc.invstd),
+                 P(wc), P(gx), P(partial), P(dwb), M, H * W, Cin, NC, P(ws), nbytes, stream())
+        grads, g_in = chain_backward(ctx.recs, ("G", gx, partial, rows), need_input_grad=ctx.needs_input_grad[0])
+        dx = ops.nchw_from_matrix(g_in, ctx.recs[0].inp.geom) if ctx.needs_input_grad[0] else None
+        return (dx, None, None, dwb[: NC * Cin].view(wc.shape), dwb[NC * Cin: NC * Cin + NC], *grads)
+
+
+def run_same_head(x, units, cls_conv, training):
+    return SameHeadFn.apply(x, list(units), training, cls_conv.weight, cls_conv.bias, *_params_of(units))
+
+
+# =================================================================================================
+class LidarFn(torch.autograd.Function):
+    """SpatialLiDAREncoder.forward_vectorized (lidar_encoder.py:57-99): point MLP on all B*N points
+    (layer 0 on VALU, layers 1-2 as MFMA GEMMs with M = B*N), BEV binning, scatter-max."""
+
+    @staticmethod
+    def forward(ctx, points, units, grid_hw, rng, training, *params):
+        ops.require_gpu_tensor(points, "LiDAREncoder")
+        B, N, D = points.shape
+        if D != 4:
+            raise KDError(f"LiDAR points must be [B, N, 4], got {tuple(points.shape)}")
+        pts = points.contiguous().view(B * N, 4)
+        cur = pts
+        recs = []
+        for u in units:
+            cur, rec = unit_forward(u, cur, training)
+            recs.append(rec)
+        H, W = grid_hw
+        C = cur.C
+        grid = torch.empty(B * H * W, C, device=pts.device, dtype=torch.float32)
+        lib.call("kd_lidar_scatter_max_fwd", P(pts), P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(grid), B, N, C, H, W,
+                 float(rng[0]), float(rng[1]), float(rng[2]), float(rng[3]), stream())
+        ctx.recs, ctx.last, ctx.pts, ctx.grid, ctx.shape, ctx.rng = recs, cur, pts, grid, (B, N, C, H, W), rng
+        return ops.nchw_from_matrix(grid, (B, H, W))
+
+    @staticmethod
+    def backward(ctx, dout):
+        dm, _ = ops.nhwc_view(dout)
+        B, N, C, H, W = ctx.shape
+        cur, pts, rng = ctx.last, ctx.pts, ctx.rng
+        dev = dm.device
+        Pn = B * N
+        G = torch.empty(Pn, C, device=dev, dtype=torch.float32)
+        rows = lib.kd_lidar_scatter_stat_rows(Pn, C)
+        partial = torch.empty(rows * 2 * C, device=dev, dtype=torch.float32)
+        nbytes = lib.kd_lidar_scatter_bwd_ws_bytes(B, H, W, C)
+        ws = ops.workspace(nbytes, dev)
+        lib.call("kd_lidar_scatter_max_bwd", P(pts), P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(ctx.grid), P(dm),
+                 P(cur.bnc.mean), P(cur.bnc.invstd), P(G), P(partial), B, N, C, H, W, float(rng[0]), float(rng[1]),
+                 float(rng[2]), float(rng[3]), P(ws), nbytes, stream())
+        grads, _ = chain_backward(ctx.recs, ("G", G, partial, rows), need_input_grad=False)
+        return (None, None, None, None, None, *grads)
+
+
+def run_lidar(points, units, grid_hw, rng, training):
+    return LidarFn.apply(points, list(units), tuple(grid_hw), tuple(rng), training, *_params_of(units))

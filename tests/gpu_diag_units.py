@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Unit-level backward localiser: small chains vs torch autograd on CPU."""
+import os, sys
+HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
+for p in (HERE, os.path.join(ROOT, "oracle"),
+          os.path.join(ROOT, "lightweight-multi-modal-scene-understanding-via-knowledge-distillation_amd")):
+    sys.path.insert(0, p)
+import copy
+import torch, torch.nn as nn
+import kd_oracle as O
+from _gpu_util import FUSIONS, build_product, load_random_state, max_err, oracle_run
+
+def rand_bn(m, g):
+    for mod in m.modules():
+        if isinstance(mod, (nn.BatchNorm2d, nn.BatchNorm1d)):
+            mod.weight.data = 0.5 + torch.rand(mod.weight.shape, generator=g)
+            mod.bias.data = 0.1 * torch.randn(mod.bias.shape, generator=g)
+
+class RefDWSep(nn.Module):       # plain torch twin with the same state_dict keys
+    def __init__(s, i, o):
+        super().__init__()
+        s.net = nn.Sequential(nn.Conv2d(i, i, 3, 1, 1, groups=i, bias=False), nn.BatchNorm2d(i), nn.ReLU(),
+                              nn.Conv2d(i, o, 1, bias=False), nn.BatchNorm2d(o), nn.ReLU())
+    def forward(s, x): return s.net(x)
+
+def check(name, prod, ref, x, zero_frac=0.0):
+    g = torch.Generator().manual_seed(3)
+    if zero_frac:
+        mask = (torch.rand(x.shape[0], 1, x.shape[2], x.shape[3], generator=g) > zero_frac).float()
+        x = x * mask
+    ref.load_state_dict(prod.state_dict()); prod = prod.cuda().train(); ref.train()
+    xg = x.clone().cuda().requires_grad_(True); xc = x.clone().requires_grad_(True)
+    y = prod(xg); yr = ref(xc)
+    up = torch.randn(yr.shape, generator=g)
+    (y * up.cuda()).sum().backward(); (yr * up).sum().backward()
+    print(f"--- {name} zero_frac={zero_frac}: out err {max_err(y, yr)[0]:.2e}  dx rel {max_err(xg.grad, xc.grad)[1]:.2e}")
+    for (n, p), (_, pr) in zip(prod.named_parameters(), ref.named_parameters()):
+        d, r = max_err(p.grad, pr.grad)
+        print(f"    {n:20s} rel {r:.2e} {'<<<<' if r > 1e-4 else ''}")
+
+def main():
+    from src.models.fusion_module import DWSeparableConv, Conv1x1
+    g = torch.Generator().manual_seed(0)
+    for zf in (0.0, 0.6):
+        for (i, o, hw) in ((64, 32, 16), (128, 64, 16), (256, 64, 16)):
+            torch.manual_seed(1)
+            prod = DWSeparableConv(i, o); rand_bn(prod, g)
+            check(f"DWSep {i}->{o} hw{hw}", prod, RefDWSep(i, o), torch.randn(2, i, hw, hw, generator=g), zf)
+    # per-channel error pattern of the first bad tensor in the minimal model
+    from kdrt.losses import seg_loss
+    B, HW, N, G = 2, 64, 512, 16
+    model = build_product("minimal", G); st = load_random_state(model, "minimal", 1); model.train()
+    images, pts, labels = O.make_inputs(B, HW, N, G, 1, pad_tail=40); cw = torch.tensor([0.4, 3.5])
+    logits = model(images.cuda(), pts.cuda()); ce, _ = seg_loss(logits, labels.cuda(), cw.cuda()); ce.backward()
+    ref = oracle_run(st, "minimal", images, pts, G, True, labels, cw)
+    for k in ("head.block.1.net.1.bias", "head.block.1.net.1.weight", "head.block.1.net.4.bias"):
+        a = dict(model.named_parameters())[k].grad.cpu(); b = ref["grads"][k]
+        print(k, "hip-oracle:", ((a - b)[:12] * 1e5).round().tolist(), " oracle:", (b[:6]).tolist())
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,193 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical seeded
+inputs, and against the golden vectors captured from the reference.  Tolerances: logits / loss
+abs 1e-4 (BASELINE.json north_star), class indices bit-exact wherever the oracle's logit margin
+exceeds the numeric tolerance, gradients 2e-4 relative to each tensor's max magnitude."""
+import numpy as np
+import pytest
+import torch
+
+import kd_oracle as O
+from _gpu_util import FUSIONS, build_product, ftol, grads_match, load_random_state, max_err, oracle_run
+from _util import golden
+
+pytestmark = pytest.mark.gpu
+B, HW, N, G = 2, 64, 512, 16
+LOGIT_TOL = 1e-4
+GRAD_RTOL = 2e-4
+
+
+@pytest.mark.parametrize("fusion", list(FUSIONS))
+def test_eval_forward_vs_oracle_and_golden(fusion):
+    model = build_product(fusion, G)
+    st = load_random_state(model, fusion, 0)
+    model.eval()
+    images, pts, _ = O.make_inputs(B, HW, N, G, 0, pad_tail=40)
+    with torch.no_grad():
+        logits, mids = model(images.cuda(), pts.cuda(), return_intermediates=True)
+        ms = model.camera_encoder(images.cuda())
+    ref = oracle_run(st, fusion, images, pts, G, training=False)
+    gd = golden(f"model_{fusion}_s0.npz")
+    for k in ("camera_feat", "lidar_feat", "pre_fusion", "post_fusion"):
+        assert max_err(mids[k], ref[k])[0] < ftol(ref[k]), k
+        assert max_err(mids[k], torch.from_numpy(gd["eval_" + k]))[0] < ftol(ref[k]), k
+    for k, v in ms.items():
+        assert max_err(v, torch.from_numpy(gd["eval_" + k]))[0] < ftol(v), k
+    assert max_err(logits, ref["logits"])[0] < ftol(ref["logits"])
+    assert max_err(logits, torch.from_numpy(gd["eval_logits"]))[0] < ftol(ref["logits"])
+    # bit-exact class indices wherever the margin is above the numeric tolerance
+    zr = ref["logits"]
+    safe = (zr[:, 0] - zr[:, 1]).abs() > 4 * ftol(zr)
+    from kdrt.losses import confusion
+    _, pred = confusion(logits, torch.zeros(B, G, G, dtype=torch.int64, device="cuda"))
+    assert torch.equal(pred.cpu()[safe], zr.argmax(1)[safe])
+    assert safe.float().mean() > 0.99
+
+
+@pytest.mark.parametrize("fusion", list(FUSIONS))
+def test_train_step_vs_oracle(fusion):
+    from kdrt.losses import confusion, seg_loss
+    model = build_product(fusion, G)
+    st = load_random_state(model, fusion, 1)
+    model.train()
+    images, pts, labels = O.make_inputs(B, HW, N, G, 1, pad_tail=40)
+    cw = torch.tensor([0.4, 3.5])
+    logits, mids = model(images.cuda(), pts.cuda(), return_intermediates=True)
+    ce, _ = seg_loss(logits, labels.cuda(), cw.cuda())
+    ce.backward()
+    ref = oracle_run(st, fusion, images, pts, G, training=True, labels=labels, cw=cw)
+    gd = golden(f"model_{fusion}_s1.npz")
+    assert max_err(logits, ref["logits"])[0] < LOGIT_TOL
+    assert max_err(logits, torch.from_numpy(gd["train_logits"]))[0] < LOGIT_TOL
+    assert abs(ce.item() - ref["loss"].item()) < LOGIT_TOL
+    assert abs(ce.item() - float(gd["train_loss"])) < LOGIT_TOL
+    bad = []
+    for name, p in model.named_parameters():
+        want = ref["grads"][name]
+        assert p.grad is not None, name
+        ok, msg = grads_match(p.grad, want)
+        if not ok:
+            bad.append((name, msg))
+    assert not bad, bad
+    # BN buffers after one training forward
+    sd = model.state_dict()
+    for k, v in ref["state"].items():
+        if k.endswith(("running_mean", "running_var")):
+            assert max_err(sd[k], v)[0] < 1e-4 * max(1.0, v.abs().max().item()), k
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v) == 1, k
+    conf, _ = confusion(logits, labels.cuda())
+    assert np.array_equal(conf.cpu().numpy(), O.confusion_matrix(ref["logits"], labels).numpy()) or \
+        (ref["logits"][:, 0] - ref["logits"][:, 1]).abs().min() < 4 * LOGIT_TOL
+
+
+def test_lidar_edge_cases_bit_exact_cells():
+    from kdrt.lib import lib
+    from kdrt.ops import P, stream
+    gd = golden("lidar_edges.npz")
+    for case in ("edge", "outside", "nan"):
+        pts = torch.from_numpy(gd[f"{case}_points"]).cuda()
+        Bn, Nn = pts.shape[:2]
+        cell = torch.empty(Bn * Nn, dtype=torch.int32, device="cuda")
+        lib.call("kd_lidar_bev_index", P(pts.view(-1, 4)), P(cell), Bn * Nn, 16, 16, -50.0, 50.0, -50.0, 50.0, stream())
+        cell = cell.cpu().numpy().reshape(Bn, Nn)
+        valid = gd[f"{case}_valid"]
+        assert np.array_equal(cell >= 0, valid)
+        flat = gd[f"{case}_flat"] % 256
+        assert np.array_equal(cell[valid], flat[valid])
+
+
+@pytest.mark.parametrize("case", ("edge", "outside"))
+def test_lidar_encoder_golden(case):
+    from src.models.lidar_encoder import SpatialLiDAREncoder
+    from _util import state_template
+    gd = golden("lidar_edges.npz")
+    full = state_template("weighted")
+    pre = "lidar_encoder.encoder."
+    st = O.randomize_state({k[len(pre):]: v for k, v in full.items() if k.startswith(pre)}, 3)
+    pts = torch.from_numpy(gd[f"{case}_points"])
+    for mode in ("eval", "train"):
+        enc = SpatialLiDAREncoder(grid_size=(16, 16))
+        st2 = dict(st); st2["grid_tensor"] = enc.state_dict()["grid_tensor"]
+        enc.load_state_dict(st2)
+        enc = enc.cuda().train(mode == "train")
+        y = enc(pts.cuda())
+        assert max_err(y, torch.from_numpy(gd[f"{case}_{mode}_out"]))[0] < LOGIT_TOL
+        if case == "outside":
+            assert float(y.abs().max()) == 0.0
+        if mode == "train" and case == "edge":
+            up = torch.from_numpy(gd[f"{case}_upstream"]).cuda()
+            (y * up).sum().backward()
+            for n_, p_ in enc.named_parameters():
+                want = torch.from_numpy(gd[f"{case}_grad_{n_}"])
+                if n_.endswith(".bias") and n_.split(".")[1] in ("0", "3", "6"):
+                    # conv bias in front of a train-mode BN: the true gradient is 0, both sides hold rounding noise
+                    assert p_.grad.abs().max().item() < 1e-4, n_
+                    continue
+                d, _ = max_err(p_.grad, want)
+                assert d < 5e-4 * max(want.abs().max().item(), 1e-3), (n_, d)
+
+
+def test_full_size_eval_golden():
+    gd = golden("full_weighted_eval.npz")
+    model = build_product("weighted", 64)
+    load_random_state(model, "weighted", 2)
+    model.eval()
+    images, pts, _ = O.make_inputs(2, 256, 5000, 64, 2, pad_tail=300)
+    with torch.no_grad():
+        logits = model(images.cuda(), pts.cuda())
+    want = torch.from_numpy(gd["logits"])
+    assert max_err(logits, want)[0] < ftol(want)
+    safe = (want[:, 0] - want[:, 1]).abs() > 4 * ftol(want)
+    assert torch.equal(logits.argmax(1).cpu()[safe], torch.from_numpy(gd["argmax"])[safe])
+
+
+def test_kd_step_vs_oracle_and_adamw():
+    from kdrt.losses import kd_objective
+    from kdrt.optim import FusedAdamW
+    teacher = build_product("concat", G)
+    t_st = load_random_state(teacher, "concat", 11)
+    teacher.eval()
+    student = build_product("weighted", G)
+    s_st = load_random_state(student, "weighted", 12)
+    student.train()
+    opt = FusedAdamW(student.parameters(), lr=1e-3, weight_decay=1e-3)
+    images, pts, labels = O.make_inputs(B, HW, N, G, 4, pad_tail=40)
+    cw = torch.tensor([0.4, 3.5])
+    with torch.no_grad():
+        zt, mt = teacher(images.cuda(), pts.cuda(), return_intermediates=True)
+    opt.zero_grad()
+    zs, ms = student(images.cuda(), pts.cuda(), return_intermediates=True)
+    total, parts = kd_objective(zs, ms, zt, mt, labels.cuda(), cw.cuda(), T=4.0, alpha=1.0, beta=1.0)
+    total.backward()
+    # oracle
+    to = O.clone_state(t_st)
+    so = O.clone_state(s_st, requires_grad=True)
+    with torch.no_grad():
+        zt_o, mt_o = O.complete_model(images, pts, to, fusion_type="concat", grid=(G, G), training=False)
+    zs_o, ms_o = O.complete_model(images, pts, so, fusion_type="weighted", grid=(G, G), training=True)
+    total_o, parts_o = O.kd_loss(zs_o, ms_o, zt_o, mt_o, labels, cw, T=4.0, alpha=1.0, beta=1.0)
+    total_o.backward()
+    gd = golden("kd_step.npz")
+    assert abs(total.item() - total_o.item()) < 2e-4
+    assert abs(total.item() - float(gd["total"])) < 2e-4
+    for k in ("ce", "kl", "mse_cam", "mse_lidar"):
+        assert abs(parts[k].item() - parts_o[k].item()) < 1e-4, k
+    bad = []
+    for name, p in student.named_parameters():
+        want = so[name].grad
+        ok, msg = grads_match(p.grad, want)
+        if not ok:
+            bad.append((name, msg))
+    assert not bad, bad
+    # one fused AdamW step vs the oracle's AdamW fed with the SAME (HIP) gradients: isolates the kernel
+    keys = O.trainable_keys(so)
+    named = dict(student.named_parameters())
+    params = [named[k].detach().cpu().clone() for k in keys]
+    grads = [named[k].grad.detach().cpu().clone() for k in keys]
+    O.adamw_step(params, grads, [torch.zeros_like(p) for p in params], [torch.zeros_like(p) for p in params], step=1,
+                 lr=1e-3, weight_decay=1e-3)
+    opt.step()
+    for k, want, g in zip(keys, params, grads):
+        tiny = g.abs() < 1e-6           # Adam turns rounding-noise gradients into +-lr: skip those elements
+        d = (named[k].detach().cpu() - want).abs()
+        assert d[~tiny].max().item() < 2e-6 * max(1.0, want.abs().max().item()) if (~tiny).any() else True, k

@@ -1,0 +1,218 @@
+"""Unit-level GPU parity: each reference module on its own, forward AND every gradient, against the
+CPU oracle at rounding-level tolerance (these problems are too small to land on a ReLU kink).
+Shapes include the awkward ones: M not a multiple of the 128-row GEMM tile, N=192 / K=32 tiles,
+odd spatial sizes under stride 2, 28x28 maps (config-1's 224^2 input)."""
+import numpy as np
+import pytest
+import torch
+
+import kd_oracle as O
+from _gpu_util import max_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5          # relative to each tensor's max magnitude
+
+
+def _rand_state(module, seed):
+    st = O.randomize_state({k: v.detach().clone() for k, v in module.state_dict().items()}, seed)
+    for k, v in module.state_dict().items():
+        if k.endswith("grid_tensor"):
+            st[k] = v.clone()
+    module.load_state_dict(st)
+    return st
+
+
+def _compare(module, oracle_fn, x, seed, training=True, x_grad=True):
+    st = _rand_state(module, seed)
+    module = module.cuda().train(training)
+    g = torch.Generator().manual_seed(100 + seed)
+    xg = x.clone().cuda().requires_grad_(x_grad)
+    y = module(xg)
+    so = O.clone_state(st, requires_grad=True)
+    xc = x.clone().requires_grad_(x_grad)
+    yo = oracle_fn(xc, so)
+    ys = y if isinstance(y, dict) else {"out": y}
+    yos = yo if isinstance(yo, dict) else {"out": yo}
+    loss = loss_o = 0.0
+    for k in yos:
+        assert ys[k].shape == yos[k].shape, k
+        d, r = max_err(ys[k], yos[k])
+        assert r < TOL, (k, d, r)
+        up = torch.randn(yos[k].shape, generator=g)
+        loss = loss + (ys[k] * up.cuda()).sum()
+        loss_o = loss_o + (yos[k] * up).sum()
+    loss.backward()
+    loss_o.backward()
+    if x_grad:
+        assert max_err(xg.grad, xc.grad)[1] < TOL, "input grad"
+    for name, p in module.named_parameters():
+        want = so[name].grad
+        assert p.grad is not None, name
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "bias" and want.abs().max() < 1e-4 * max(1.0, float(loss_o.detach().abs()) ** 0.5):
+            assert p.grad.abs().max().item() < 1e-3, name     # zero-gradient conv bias in front of a BN: noise
+            continue
+        d, r = max_err(p.grad, want)
+        assert r < 5 * TOL, (name, d, r)
+    for k, v in so.items():
+        if k.endswith(("running_mean", "running_var")):
+            assert max_err(module.state_dict()[k], v)[1] < 1e-5, k
+
+
+@pytest.mark.parametrize("cin,cout,stride,exp,hw", [(32, 32, 1, 1, 16), (32, 64, 2, 6, 14), (64, 64, 1, 6, 7),
+                                                     (64, 128, 2, 6, 7), (128, 128, 1, 6, 4)])
+@pytest.mark.parametrize("training", (True, False))
+def test_inverted_residual(cin, cout, stride, exp, hw, training):
+    from src.models.camera_encoder import InvertedResidual
+    torch.manual_seed(0)
+    m = InvertedResidual(cin, cout, stride=stride, expansion_ratio=exp)
+    x = torch.randn(3, cin, hw, hw, generator=torch.Generator().manual_seed(1))
+    _compare(m, lambda xx, st: O.inverted_residual(xx, st, "", cin, cout, stride, exp, training)
+             if False else O.inverted_residual(xx, {("." + k): v for k, v in st.items()}, "", cin, cout, stride, exp, training),
+             x, seed=cin + stride, training=training)
+
+
+@pytest.mark.parametrize("hw", (32, 28))
+def test_twinlite_encoder_multiscale(hw):
+    from src.models.camera_encoder import TwinLiteEncoder
+    m = TwinLiteEncoder(return_multiscale=True)
+    x = torch.rand(2, 3, hw, hw, generator=torch.Generator().manual_seed(2))
+    _compare(m, lambda xx, st: O.twinlite_encoder(xx, st, "", True, True), x, seed=5, x_grad=False)
+
+
+def test_twinlite_config1_shape_and_eval():
+    """BASELINE configs[0]: TwinLiteEncoder() on a 4x3x224x224 batch (shape pin test_camera_encoder.py:24-40)."""
+    from src.models.camera_encoder import TwinLiteEncoder
+    m = TwinLiteEncoder()
+    st = _rand_state(m, 9)
+    m = m.cuda().eval()
+    x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        y = m(x.cuda())
+        yo = O.twinlite_encoder(x, O.clone_state(st), "", False, False)
+    assert y.shape == (4, 128, 28, 28)
+    assert max_err(y, yo)[1] < TOL
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 128), (256, 64)])
+def test_conv1x1_and_dwsep(cin, cout):
+    from src.models.fusion_module import Conv1x1, DWSeparableConv
+    x = torch.randn(2, cin, 12, 12, generator=torch.Generator().manual_seed(3))
+    _compare(Conv1x1(cin, cout), lambda xx, st: O.conv1x1_block(xx, {("m." + k): v for k, v in st.items()}, "m", True), x, 11)
+    _compare(DWSeparableConv(cin, cout), lambda xx, st: O.dwsep_block(xx, {("m." + k): v for k, v in st.items()}, "m", True), x, 12)
+
+
+def test_camera_fpn():
+    from src.models.fusion_module import CameraFPNLite
+    stages = ["stage3", "stage4", "stage5"]
+    fpn = CameraFPNLite({"stage2": 64, "stage3": 64, "stage4": 128, "stage5": 128}, 128, stages)
+    st = _rand_state(fpn, 21)
+    fpn = fpn.cuda().train()
+    g = torch.Generator().manual_seed(4)
+    feats = {"stage3": torch.randn(2, 64, 12, 12, generator=g), "stage4": torch.randn(2, 128, 6, 6, generator=g),
+             "stage5": torch.randn(2, 128, 6, 6, generator=g)}
+    fg = {k: v.clone().cuda().requires_grad_(True) for k, v in feats.items()}
+    fc = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    y = fpn(fg)
+    so = O.clone_state(st, requires_grad=True)
+    yo = O.camera_fpn(fc, {("f." + k): v for k, v in so.items()}, "f", stages, True)
+    assert max_err(y, yo)[1] < TOL
+    up = torch.randn(yo.shape, generator=g)
+    (y * up.cuda()).sum().backward()
+    (yo * up).sum().backward()
+    for k in feats:
+        assert max_err(fg[k].grad, fc[k].grad)[1] < 5 * TOL, k
+    for name, p in fpn.named_parameters():
+        assert max_err(p.grad, so[name].grad)[1] < 5 * TOL, name
+
+
+@pytest.mark.parametrize("n,grid,pad", [(300, 8, 0), (1000, 16, 200)])
+def test_lidar_encoder(n, grid, pad):
+    from src.models.lidar_encoder import LiDAREncoder
+    enc = LiDAREncoder(encoder_type="spatial", grid_size=(grid, grid))
+    st = _rand_state(enc, 31)
+    enc = enc.cuda().train()
+    _, pts, _ = O.make_inputs(2, 8, n, grid, 7, pad_tail=pad)
+    y = enc(pts.cuda())
+    so = O.clone_state(st, requires_grad=True)
+    yo = O.spatial_lidar_encoder(pts, so, "encoder.", (grid, grid), True)
+    assert max_err(y, yo)[1] < TOL
+    up = torch.randn(yo.shape, generator=torch.Generator().manual_seed(8))
+    (y * up.cuda()).sum().backward()
+    (yo * up).sum().backward()
+    for name, p in enc.named_parameters():
+        want = so[name].grad
+        if name.endswith(("point_mlp.0.bias", "point_mlp.3.bias", "point_mlp.6.bias")):
+            assert p.grad.abs().max().item() < 1e-3, name
+            continue
+        assert max_err(p.grad, want)[1] < 5 * TOL, name
+
+
+@pytest.mark.parametrize("fusion", ("concat", "minimal", "weighted"))
+def test_fusion_and_head_small(fusion):
+    """Fusion block + head driven through the full-model oracle with tiny encoders' outputs replaced
+    by random feature maps: isolates fusion_module.py:242-258."""
+    from src.models.fusion_module import (ConcatenationFusion, MinimalFusion, SameResolutionSegmentationHead,
+                                          WeightedFusion)
+    torch.manual_seed(0)
+    fus = {"concat": lambda: ConcatenationFusion(128, 128, 256), "minimal": lambda: MinimalFusion(128, 128, 128),
+           "weighted": lambda: WeightedFusion(128, 128, 128)}[fusion]()
+    head = SameResolutionSegmentationHead(256 if fusion == "concat" else 128, 2)
+    stf, sth = _rand_state(fus, 41), _rand_state(head, 42)
+    fus, head = fus.cuda().train(), head.cuda().train()
+    g = torch.Generator().manual_seed(6)
+    cam, lid = torch.randn(2, 128, 10, 10, generator=g), torch.randn(2, 128, 10, 10, generator=g).clamp_min(0)
+    cg, lg = cam.clone().cuda().requires_grad_(True), lid.clone().cuda().requires_grad_(True)
+    cc, lc = cam.clone().requires_grad_(True), lid.clone().requires_grad_(True)
+    z = head(fus(cg, lg))
+    so = O.clone_state({**{"fusion." + k: v for k, v in stf.items()}, **{"head." + k: v for k, v in sth.items()}}, True)
+    # oracle: reuse complete_model's fusion/head section by calling the pieces directly
+    if fusion == "concat":
+        cp = O.conv1x1_block(cc, so, "fusion.camera_proj", True); lp = O.conv1x1_block(lc, so, "fusion.lidar_proj", True)
+        h = O._dw_bn_act(torch.cat([cp, lp], 1), so, "fusion.fuse.0", "fusion.fuse.1", "relu", 1, True)
+        fused = O._pw_bn_act(h, so, "fusion.fuse.3", "fusion.fuse.4", "relu", True)
+    else:
+        cp = O.conv1x1_block(cc, so, "fusion.cam_proj", True); lp = O.conv1x1_block(lc, so, "fusion.lidar_proj", True)
+        if fusion == "weighted":
+            import torch.nn.functional as F
+            a = F.conv2d(torch.cat([cp, lp], 1), so["fusion.attention.0.weight"], so["fusion.attention.0.bias"])
+            a = F.conv2d(a.clamp_min(0), so["fusion.attention.2.weight"], so["fusion.attention.2.bias"])
+            w = torch.softmax(a, 1)
+            fused = cp * w[:, 0:1] + lp * w[:, 1:2]
+        else:
+            fused = cp + lp
+    zo = O.seg_head_same(fused, so, "head", True)
+    assert max_err(z, zo)[1] < TOL
+    up = torch.randn(zo.shape, generator=g)
+    (z * up.cuda()).sum().backward()
+    (zo * up).sum().backward()
+    assert max_err(cg.grad, cc.grad)[1] < 5 * TOL and max_err(lg.grad, lc.grad)[1] < 5 * TOL
+    for pre, mod in (("fusion.", fus), ("head.", head)):
+        for name, p in mod.named_parameters():
+            assert max_err(p.grad, so[pre + name].grad)[1] < 5 * TOL, pre + name
+
+
+def test_losses_and_confusion():
+    from kdrt.losses import confusion, feature_mse, seg_loss
+    g = torch.Generator().manual_seed(9)
+    for nc in (2, 3):
+        zs, zt = torch.randn(3, nc, 9, 7, generator=g) * 3, torch.randn(3, nc, 9, 7, generator=g) * 3
+        y = torch.randint(0, nc, (3, 9, 7), generator=g); y[0, 0, :4] = -1
+        cw = torch.rand(nc, generator=g) + 0.2
+        zg, zc = zs.clone().cuda().requires_grad_(True), zs.clone().requires_grad_(True)
+        ce, kl = seg_loss(zg, y.cuda(), cw.cuda(), -1, zt.cuda(), T=4.0, alpha=0.7)
+        ce_o = O.weighted_ce(zc, y, cw)
+        ps_log, pt = torch.log_softmax(zc / 4, 1), torch.softmax(zt / 4, 1)
+        kl_o = (pt * (torch.log_softmax(zt / 4, 1) - ps_log)).sum() / (3 * 9 * 7)
+        assert abs(ce.item() - ce_o.item()) < 1e-5 and abs(kl.item() - kl_o.item()) < 1e-6
+        (2.5 * ce).backward()
+        (2.5 * (ce_o + 0.7 * 16 * kl_o)).backward()
+        assert max_err(zg.grad, zc.grad)[1] < TOL
+        conf, pred = confusion(zs.cuda(), y.cuda(), num_classes=nc)
+        assert torch.equal(pred.cpu(), zs.argmax(1))
+        assert np.array_equal(conf.cpu().numpy(), O.confusion_matrix(zs, y, nc).numpy())
+    a, b = torch.randn(2, 16, 5, 6, generator=g), torch.randn(2, 16, 5, 6, generator=g)
+    ag, ac = a.clone().cuda().requires_grad_(True), a.clone().requires_grad_(True)
+    (3.0 * feature_mse(ag, b.cuda())).backward()
+    (3.0 * torch.nn.functional.mse_loss(ac, b)).backward()
+    assert max_err(ag.grad, ac.grad)[1] < TOL
