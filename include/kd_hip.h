@@ -83,7 +83,7 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
                      void* stream);
 
 /* ---- BatchNorm coefficient kernels (nn.BatchNorm1d/2d: eps 1e-5, momentum 0.1) ---------------- */
-int kd_bn_finalize_train(const float* partial, int rows, int C, int pstride, int64_t count, const float* gamma,
+int kd_bn_finalize_train(float* partial, int rows, int C, int pstride, int64_t count, const float* gamma,
                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                          int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
                          void* stream);
@@ -95,7 +95,7 @@ int kd_bn_act_apply(const float* x, int64_t ldx, const float* sc, const float* s
 int kd_bn_bwd_reduce(const float* D, int64_t ldd, const float* X, int64_t ldx, const float* sc, const float* sh,
                      int act, const float* mean, const float* invstd, float* partial, int64_t M, int C,
                      void* stream);
-int kd_bn_bwd_finalize(const float* partial, int rows, int C, int pstride, int64_t count, const float* gamma, const float* mean,
+int kd_bn_bwd_finalize(float* partial, int rows, int C, int pstride, int64_t count, const float* gamma, const float* mean,
                        const float* invstd, int training, float* dgamma, float* dbeta, float* al, float* be,
                        float* ga, float* dbias, void* stream);
 

@@ -11,13 +11,48 @@
 namespace {
 
 // grid.x = ceil(C/64); block (64, 4): 4 row lanes per channel
-__device__ __forceinline__ void reduce_slab2(const float* partial, int rows, int C, int pstride, int c, double& s1,
-                                             double& s2, double (*sm)[2][64]) {
+// Stage 1 of the slab reduction (only for tall slabs): every group of `group` consecutive rows is
+// summed IN PLACE into the group's first row, so the finalize kernels below walk rows/group rows
+// instead of serialising thousands of dependent loads in a handful of workgroups.
+// grid (ceil(C/64), ceil(rows/group)), block (64, 4).  The slab is scratch: clobbering it is fine.
+__global__ void slab_prereduce_kernel(float* partial, int rows, int C, int pstride, int group) {
+  __shared__ double sm[4][2][64];
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int r0 = blockIdx.y * group;
+  const int r1 = r0 + group < rows ? r0 + group : rows;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int r = r0 + threadIdx.y; r < r1; r += 4) {
+      a += (double)partial[((int64_t)r * 2 + 0) * pstride + c];
+      b += (double)partial[((int64_t)r * 2 + 1) * pstride + c];
+    }
+  sm[threadIdx.y][0][threadIdx.x] = a;
+  sm[threadIdx.y][1][threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.y == 0 && c < C) {
+    partial[((int64_t)r0 * 2 + 0) * pstride + c] = (float)(sm[0][0][threadIdx.x] + sm[1][0][threadIdx.x] + sm[2][0][threadIdx.x] + sm[3][0][threadIdx.x]);
+    partial[((int64_t)r0 * 2 + 1) * pstride + c] = (float)(sm[0][1][threadIdx.x] + sm[1][1][threadIdx.x] + sm[2][1][threadIdx.x] + sm[3][1][threadIdx.x]);
+  }
+}
+
+// returns the row step the finalize kernel must use (1 = slab untouched)
+static int slab_prereduce(float* partial, int& rows, int C, int pstride, hipStream_t st) {
+  if (rows <= 64) return 1;
+  int group = 1;
+  while (group * group < rows) ++group;                      // ~sqrt(rows)
+  const int ngroups = (rows + group - 1) / group;
+  hipLaunchKernelGGL(slab_prereduce_kernel, dim3((C + 63) / 64, ngroups), dim3(64, 4), 0, st, partial, rows, C, pstride, group);
+  rows = ngroups;
+  return group;
+}
+
+__device__ __forceinline__ void reduce_slab2(const float* partial, int rows, int rstep, int C, int pstride, int c,
+                                             double& s1, double& s2, double (*sm)[2][64]) {
   double a = 0.0, b = 0.0;
   if (c < C)
     for (int r = threadIdx.y; r < rows; r += 4) {
-      a += (double)partial[((int64_t)r * 2 + 0) * pstride + c];
-      b += (double)partial[((int64_t)r * 2 + 1) * pstride + c];
+      a += (double)partial[((int64_t)r * rstep * 2 + 0) * pstride + c];
+      b += (double)partial[((int64_t)r * rstep * 2 + 1) * pstride + c];
     }
   sm[threadIdx.y][0][threadIdx.x] = a;
   sm[threadIdx.y][1][threadIdx.x] = b;
@@ -26,14 +61,14 @@ __device__ __forceinline__ void reduce_slab2(const float* partial, int rows, int
   s2 = sm[0][1][threadIdx.x] + sm[1][1][threadIdx.x] + sm[2][1][threadIdx.x] + sm[3][1][threadIdx.x];
 }
 
-__global__ void bn_finalize_train_kernel(const float* partial, int rows, int C, int pstride, double count, const float* gamma,
+__global__ void bn_finalize_train_kernel(const float* partial, int rows, int rstep, int C, int pstride, double count, const float* gamma,
                                          const float* beta, float eps, float momentum, float* running_mean,
                                          float* running_var, int64_t* nbt, float* mean, float* invstd, float* scale,
                                          float* shift) {
   __shared__ double sm[4][2][64];
   const int c = blockIdx.x * 64 + threadIdx.x;
   double s1, s2;
-  reduce_slab2(partial, rows, C, pstride, c, s1, s2, sm);
+  reduce_slab2(partial, rows, rstep, C, pstride, c, s1, s2, sm);
   if (threadIdx.y != 0 || c >= C) return;
   const double mu = s1 / count;
   double var = s2 / count - mu * mu;
@@ -67,13 +102,13 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
   shift[c] = fmaf(-rm[c], sc, b);
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* partial, int rows, int C, int pstride, double count, const float* gamma,
+__global__ void bn_bwd_finalize_kernel(const float* partial, int rows, int rstep, int C, int pstride, double count, const float* gamma,
                                        const float* mean, const float* invstd, int training, float* dgamma,
                                        float* dbeta, float* al, float* be, float* ga, float* dbias) {
   __shared__ double sm[4][2][64];
   const int c = blockIdx.x * 64 + threadIdx.x;
   double s1, s2;
-  reduce_slab2(partial, rows, C, pstride, c, s1, s2, sm);
+  reduce_slab2(partial, rows, rstep, C, pstride, c, s1, s2, sm);
   if (threadIdx.y != 0 || c >= C) return;
   if (dbeta) dbeta[c] = (float)s1;
   if (dgamma) dgamma[c] = (float)s2;
@@ -163,12 +198,13 @@ extern "C" {
 
 // Batch statistics -> forward coefficients; updates running stats / num_batches_tracked in place
 // (pass null to skip).  partial: [rows][2][C] holding (sum, sum of squares) over `count` samples.
-int kd_bn_finalize_train(const float* partial, int rows, int C, int pstride, int64_t count, const float* gamma, const float* beta,
+int kd_bn_finalize_train(float* partial, int rows, int C, int pstride, int64_t count, const float* gamma, const float* beta,
                          float eps, float momentum, float* running_mean, float* running_var, int64_t* nbt,
                          float* mean, float* invstd, float* scale, float* shift, void* stream) {
   KD_REQUIRE(partial && rows > 0 && C > 0 && pstride >= C && count > 0 && mean && invstd && scale && shift, KD_ERR_ARG, "kd_bn_finalize_train: bad args");
+  const int rstep = slab_prereduce(partial, rows, C, pstride, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 63) / 64), dim3(64, 4), 0, (hipStream_t)stream, partial, rows,
-                     C, pstride, (double)count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd, scale,
+                     rstep, C, pstride, (double)count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd, scale,
                      shift);
   return kd_check_launch("kd_bn_finalize_train");
 }
@@ -205,12 +241,13 @@ int kd_bn_bwd_reduce(const float* D, int64_t ldd, const float* X, int64_t ldx, c
   return kd_check_launch("kd_bn_bwd_reduce");
 }
 
-int kd_bn_bwd_finalize(const float* partial, int rows, int C, int pstride, int64_t count, const float* gamma, const float* mean,
+int kd_bn_bwd_finalize(float* partial, int rows, int C, int pstride, int64_t count, const float* gamma, const float* mean,
                        const float* invstd, int training, float* dgamma, float* dbeta, float* al, float* be,
                        float* ga, float* dbias, void* stream) {
   KD_REQUIRE(partial && rows > 0 && C > 0 && pstride >= C && count > 0 && mean && invstd && al && be && ga, KD_ERR_ARG, "kd_bn_bwd_finalize: bad args");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64, 4), 0, (hipStream_t)stream, partial, rows, C,
-                     pstride, (double)count, gamma, mean, invstd, training, dgamma, dbeta, al, be, ga, dbias);
+  const int rstep = slab_prereduce(partial, rows, C, pstride, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64, 4), 0, (hipStream_t)stream, partial, rows,
+                     rstep, C, pstride, (double)count, gamma, mean, invstd, training, dgamma, dbeta, al, be, ga, dbias);
   return kd_check_launch("kd_bn_bwd_finalize");
 }
 

@@ -115,55 +115,72 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs g) {
     }
   }
 
-  // ---- epilogue -------------------------------------------------------------------------------
-  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  // ---- epilogue ---------------------------------------------------------------------------------
+  // The accumulator tile goes through LDS in two 64-row halves so that C stores and the X / addend
+  // loads are whole 512-byte rows (float4 per lane) instead of 4-byte column-strided accesses.
+  constexpr int TLD = 132;
+  float* T = smem;                                   // [64][TLD] staging (33.8 KB of the 36.9 KB)
+  const int c4 = tid & 31, rg = tid >> 5;            // this thread's 4 columns / row group
+  const int col = n0 + c4 * 4;
+  const bool cok = col < g.N;
+  float4 bias4 = kd_zero4(), esc = kd_zero4(), esh = kd_zero4(), emean = kd_zero4(), einv = kd_zero4();
+  if (cok) {
+    if (g.bias) bias4 = kd_ld4(g.bias + col);
+    if (EPI == 2) { esc = kd_ld4(g.esc + col); esh = kd_ld4(g.esh + col); emean = kd_ld4(g.emean + col); einv = kd_ld4(g.einv + col); }
+  }
+  float4 s1 = kd_zero4(), s2 = kd_zero4();
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int col = n0 + wc * 64 + ni * 32 + (lane & 31);
-    const bool cok = col < g.N;
-    float bias = 0.f, esc = 0.f, esh = 0.f, emean = 0.f, einv = 0.f;
-    if (cok) {
-      if (g.bias) bias = g.bias[col];
-      if (EPI == 2) { esc = g.esc[col]; esh = g.esh[col]; emean = g.emean[col]; einv = g.einv[col]; }
-    }
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();                                 // LDS free: K-loop reads / previous half done
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (cok && row < g.M) {
-          float v = acc[mi][ni][r] + bias;
-          if (g.addend) v += g.addend[row * g.ldadd + col];
-          if (EPI == 2) {
-            const float x = g.X[row * g.ldx + col];
-            v *= kd_act_mask(kd_affine(x, esc, esh), g.epi_act);
-            s1[ni] += v;
-            s2[ni] += v * ((x - emean) * einv);
-          } else if (EPI == 1) {
-            s1[ni] += v;
-            s2[ni] += v * v;
-          }
-          g.C[row * g.ldc + col] = v;
+      for (int r = 0; r < 16; ++r)
+        T[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TLD + wc * 64 + ni * 32 + (lane & 31)] = acc[h][ni][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rr = rg + 8 * i;
+      const int64_t row = m0 + (rr >> 5) * 64 + h * 32 + (rr & 31);
+      if (cok && row < g.M) {
+        float4 v = kd_ld4(T + rr * TLD + c4 * 4);
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (g.addend) {
+          const float4 ad = kd_ld4(g.addend + row * g.ldadd + col);
+          v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
         }
+        if (EPI == 2) {
+          const float4 x = kd_ld4(g.X + row * g.ldx + col);
+          v.x *= kd_act_mask(kd_affine(x.x, esc.x, esh.x), g.epi_act);
+          v.y *= kd_act_mask(kd_affine(x.y, esc.y, esh.y), g.epi_act);
+          v.z *= kd_act_mask(kd_affine(x.z, esc.z, esh.z), g.epi_act);
+          v.w *= kd_act_mask(kd_affine(x.w, esc.w, esh.w), g.epi_act);
+          s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+          s2.x = fmaf(v.x, (x.x - emean.x) * einv.x, s2.x);
+          s2.y = fmaf(v.y, (x.y - emean.y) * einv.y, s2.y);
+          s2.z = fmaf(v.z, (x.z - emean.z) * einv.z, s2.z);
+          s2.w = fmaf(v.w, (x.w - emean.w) * einv.w, s2.w);
+        } else if (EPI == 1) {
+          s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+          s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+        }
+        kd_st4(g.C + row * g.ldc + col, v);
       }
     }
   }
   if (EPI != 0) {
-    __syncthreads();                               // everyone is done reading As/Bs
-    float* red = smem;                             // [wr][stat][128]
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      float a1 = s1[ni] + __shfl_xor(s1[ni], 32, 64);
-      float a2 = s2[ni] + __shfl_xor(s2[ni], 32, 64);
-      if (lane < 32) {
-        red[(wr * 2 + 0) * 128 + wc * 64 + ni * 32 + lane] = a1;
-        red[(wr * 2 + 1) * 128 + wc * 64 + ni * 32 + lane] = a2;
-      }
-    }
     __syncthreads();
-    const int st = tid >> 7, c = tid & 127;        // 256 threads = 2 stats x 128 columns
-    if (n0 + c < g.N)
-      g.partial[((int64_t)rowblk * 2 + st) * g.N + n0 + c] = red[(0 * 2 + st) * 128 + c] + red[(1 * 2 + st) * 128 + c];
+    float* red = smem;                               // [8 row groups][2 stats][128 columns]
+    kd_st4(red + (rg * 2 + 0) * 128 + c4 * 4, s1);
+    kd_st4(red + (rg * 2 + 1) * 128 + c4 * 4, s2);
+    __syncthreads();
+    const int st = tid >> 7, c = tid & 127;          // 256 threads = 2 stats x 128 columns
+    if (n0 + c < g.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += red[(k * 2 + st) * 128 + c];
+      g.partial[((int64_t)rowblk * 2 + st) * g.N + n0 + c] = s;
+    }
   }
 }
 
@@ -359,7 +376,10 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
   KD_REQUIRE(A && W && C && M > 0 && K > 0 && N > 0, KD_ERR_ARG, "kd_pwconv_gemm: null pointer or empty shape");
   KD_REQUIRE(M < (int64_t)1 << 31, KD_ERR_SHAPE, "kd_pwconv_gemm: M=%lld too large", (long long)M);
   KD_REQUIRE(K % 4 == 0 && lda % 4 == 0, KD_ERR_SHAPE, "kd_pwconv_gemm: K=%d and lda=%lld must be multiples of 4", K, (long long)lda);
-  KD_REQUIRE(kd_aligned16(A) && kd_aligned16(W), KD_ERR_ALIGN, "kd_pwconv_gemm: A/W must be 16-byte aligned");
+  KD_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && (!addend || ldadd % 4 == 0) && (!X || ldx % 4 == 0), KD_ERR_SHAPE,
+             "kd_pwconv_gemm: N=%d and the output-side row strides must be multiples of 4", N);
+  KD_REQUIRE(kd_aligned16(A) && kd_aligned16(W) && kd_aligned16(C) && kd_aligned16(addend) && kd_aligned16(X) &&
+             kd_aligned16(bias), KD_ERR_ALIGN, "kd_pwconv_gemm: A/W/C/addend/X/bias must be 16-byte aligned");
   KD_REQUIRE(pro >= 0 && pro <= 2 && epi >= 0 && epi <= 2, KD_ERR_ARG, "kd_pwconv_gemm: bad pro/epi");
   if (pro == 1) KD_REQUIRE(p0 && p1 && kd_aligned16(p0) && kd_aligned16(p1), KD_ERR_ARG, "kd_pwconv_gemm: PRO1 needs sc/sh");
   if (pro == 2) {

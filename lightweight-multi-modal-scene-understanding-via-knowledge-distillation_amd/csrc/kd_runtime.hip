@@ -22,17 +22,28 @@ int kd_check_launch(const char* what) {
 }
 
 namespace {
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, int64_t n, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// out[i] = sum_k slab[k][i].  Block (64 elements, 16 split lanes): the split dimension is walked by
+// 16 lanes in parallel and combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, int64_t n,
+                                                           float* __restrict__ out) {
+  __shared__ float sm[16][64];
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += slab[(int64_t)k * n + i];
-  out[i] = s;
+  if (i < n)
+    for (int k = threadIdx.y; k < nsplit; k += 16) s += slab[(int64_t)k * n + i];
+  sm[threadIdx.y][threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.y == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][threadIdx.x];
+    out[i] = t;
+  }
 }
 }  // namespace
 
 int kd_slab_reduce_launch(const float* slab, int nsplit, int64_t n, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsplit, n, out);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64, 16), 0, st, slab, nsplit, n, out);
   return kd_check_launch("kd_slab_reduce");
 }
 

@@ -1,0 +1,100 @@
+"""Data-parallel gradient exchange: bucketed asynchronous all-reduce over RCCL (xGMI), overlapped
+with the rest of backward.
+
+The reference is single-process (no torch.distributed anywhere), so this is new
+work defined by BASELINE.json's north_star: one process per GPU, the batch sharded over ranks,
+student gradients summed with `all_reduce` and divided by world size inside the fused AdamW kernel.
+Semantics == k independent reference replicas on k micro-batches with averaged gradients
+(per-rank BatchNorm statistics; the reference has no SyncBN).
+
+Gradients live in ONE flat buffer (optim.FlatParams); a bucket is a contiguous slice of it.  The
+payload is ~2.1 MB fp32 -- latency-bound on xGMI -- so there are only a few buckets, cut at
+module boundaries in backward-completion order (head -> fusion -> FPN/LiDAR -> camera stages), and
+each is launched from an autograd hook the moment its last gradient has been accumulated, so the
+reduce of the late layers flies under the camera encoder's backward.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .optim import FlatParams
+
+
+def broadcast_module(module: torch.nn.Module, src: int = 0, group=None):
+    """One-time parameter + buffer broadcast from rank `src` (like DDP's init)."""
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+class BucketedAllReduce:
+    def __init__(self, flat: FlatParams, names: Optional[Sequence[str]] = None, n_buckets: int = 3, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        n = len(flat.params)
+        # bucket boundaries (parameter indices), contiguous in registration order; cut where the
+        # top-level module name changes, then merged down to n_buckets of similar byte size
+        cuts = [0]
+        if names is not None:
+            tops = [nm.split(".")[0] for nm in names]
+            cuts += [i for i in range(1, n) if tops[i] != tops[i - 1]]
+        cuts.append(n)
+        spans = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
+        while len(spans) > n_buckets:                   # merge the smallest neighbouring pair
+            sizes = [flat.offsets[b] - flat.offsets[a] for a, b in spans]
+            j = min(range(len(spans) - 1), key=lambda i: sizes[i] + sizes[i + 1])
+            spans[j:j + 2] = [(spans[j][0], spans[j + 1][1])]
+        self.spans = spans
+        self.bucket_of = [0] * n
+        for b, (a, e) in enumerate(spans):
+            for i in range(a, e):
+                self.bucket_of[i] = b
+        self.views = [flat.grad[flat.offsets[a]:flat.offsets[e]] for a, e in spans]
+        self.pending = [0] * len(spans)
+        self.handles: List = []
+        self.comm_stream = torch.cuda.Stream() if flat.grad.is_cuda else None
+        for i, p in enumerate(flat.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+        self.launch_order: List[int] = []
+        self.reset()
+
+    def reset(self):
+        for b, (a, e) in enumerate(self.spans):
+            self.pending[b] = e - a
+        self.handles = []
+        self.launch_order = []
+
+    def _make_hook(self, i):
+        def hook(_p):
+            b = self.bucket_of[i]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        self.launch_order.append(b)
+        if self.world == 1:
+            return
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                h = dist.all_reduce(self.views[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            h = dist.all_reduce(self.views[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.handles.append(h)
+
+    def finish(self):
+        """Call after backward: launches any bucket whose hooks did not all fire (unused parameters),
+        waits for the reductions, and makes the compute stream wait for the comm stream."""
+        for b in range(len(self.spans)):
+            if self.pending[b] > 0:
+                self._launch(b)
+        for h in self.handles:
+            h.wait()
+        if self.comm_stream is not None and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.reset()
+        return 1.0 / self.world           # the factor the optimiser applies to the summed gradients

@@ -112,20 +112,44 @@ def bn_eval_coeffs(bn, bnc: BNC):
              P(bnc.mean), P(bnc.invstd), P(bnc.scale), P(bnc.shift), stream())
 
 
+PROFILE = None      # bench.py sets this to a list to time GEMM launches with HIP events on the launch stream
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, kind, flops, nbytes):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((kind, flops, nbytes, e0, e1))
+
+
 def pw_gemm(A, W, C_out, *, M, K, N, A2=None, pro=0, pro_act=0, p=(None,) * 5, bias=None, addend=None, epi=0,
             X=None, esc=None, esh=None, emean=None, einv=None, epi_act=0, partial=None):
+    e0 = _prof_begin()
     lib.call("kd_pwconv_gemm", P(A), ld(A), P(A2), ld(A2) if A2 is not None else 0, pro, pro_act,
              P(p[0]), P(p[1]), P(p[2]), P(p[3]), P(p[4]), P(W), P(bias), P(C_out), ld(C_out),
              P(addend), ld(addend) if addend is not None else 0, epi, P(X), ld(X) if X is not None else 0,
              P(esc), P(esh), P(emean), P(einv), epi_act, P(partial), M, K, N, stream())
+    # algorithmic bytes: every operand tensor of the launch read or written exactly once
+    _prof_end(e0, "pw_gemm", 2.0 * M * N * K,
+              4.0 * (M * K * (2 if pro == 2 else 1) + M * N * (1 + (epi == 2) + (addend is not None)) + N * K))
 
 
 def pw_wgrad(D, A, dW, *, M, N, K, X=None, d_mode=0, d_act=0, al=None, be=None, ga=None, msc=None, msh=None,
              a_mode=0, a_act=0, asc=None, ash=None):
     nbytes = lib.kd_pwconv_wgrad_ws_bytes(M, N, K)
     ws = workspace(nbytes, D.device)
+    e0 = _prof_begin()
     lib.call("kd_pwconv_wgrad", P(D), ld(D), P(X), ld(X) if X is not None else 0, d_mode, d_act, P(al), P(be), P(ga),
              P(msc), P(msh), P(A), ld(A), a_mode, a_act, P(asc), P(ash), P(dW), M, N, K, P(ws), nbytes, stream())
+    _prof_end(e0, "pw_wgrad", 2.0 * M * N * K, 4.0 * (M * N * (2 if d_mode == 2 else 1) + M * K + N * K))
 
 
 def transpose(w2d: torch.Tensor) -> torch.Tensor:
