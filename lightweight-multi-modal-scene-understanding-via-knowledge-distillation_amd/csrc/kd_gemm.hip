@@ -32,7 +32,7 @@ struct GemmArgs {
   int M, K, N;
 };
 
-template <int EPI>
+template <int PRO, int EPI>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 128 * LDSLD];
   float* As = smem;
@@ -65,9 +65,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs g) {
       float4 va = kd_zero4();
       if (gm < g.M && gk < g.K) {
         va = kd_ld4(g.A + gm * g.lda + gk);
-        if (g.pro == 1) {
+        if (PRO == 1) {
           va = kd_affine_act4(va, kd_ld4(g.p0 + gk), kd_ld4(g.p1 + gk), g.pro_act);
-        } else if (g.pro == 2) {
+        } else if (PRO == 2) {
           const float4 x = kd_ld4(g.A2 + gm * g.lda2 + gk);
           const float4 al = kd_ld4(g.p0 + gk), be = kd_ld4(g.p1 + gk), ga = kd_ld4(g.p2 + gk);
           float4 sc = kd_zero4(), sh = kd_zero4();
@@ -199,7 +199,7 @@ struct WgradArgs {
   int rows_per_split;                 // multiple of the chunk height
 };
 
-template <int WN, int WK, int WM>
+template <int WN, int WK, int WM, int DMODE, int AMODE>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs g) {
   constexpr int TN = 64 * WN, TK = 64 * WK, CH = 32 * WM;
   constexpr int DF4 = CH * TN / 1024, AF4 = CH * TK / 1024;     // float4 per thread per chunk
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs g) {
       float4 v = kd_zero4();
       if (gm < mend && gn < g.N) {
         v = kd_ld4(g.D + gm * g.ldd + gn);
-        if (g.d_mode == 2) {
+        if (DMODE == 2) {
           const float4 x = kd_ld4(g.X + gm * g.ldx + gn);
           const float4 al = kd_ld4(g.al + gn), be = kd_ld4(g.be + gn), ga = kd_ld4(g.ga + gn);
           float4 sc = kd_zero4(), sh = kd_zero4();
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs g) {
       float4 v = kd_zero4();
       if (gm < mend && gk < g.K) {
         v = kd_ld4(g.A + gm * g.lda + gk);
-        if (g.a_mode == 1) v = kd_affine_act4(v, kd_ld4(g.asc + gk), kd_ld4(g.ash + gk), g.a_act);
+        if (AMODE == 1) v = kd_affine_act4(v, kd_ld4(g.asc + gk), kd_ld4(g.ash + gk), g.a_act);
       }
       ra[i] = v;
     }
@@ -356,7 +356,11 @@ int launch_wgrad(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
   int64_t cps = (chunks + nsplit - 1) / nsplit;
   g.rows_per_split = (int)(cps * CH);
   nsplit = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
-  hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM>), dim3(ntiles * nsplit), dim3(256), 0, st, g);
+  const dim3 grid(ntiles * nsplit), blk(256);
+  if (g.d_mode == 2 && g.a_mode == 1) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 1>), grid, blk, 0, st, g);
+  else if (g.d_mode == 2) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 0>), grid, blk, 0, st, g);
+  else if (g.a_mode == 1) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 0, 1>), grid, blk, 0, st, g);
+  else hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 0, 0>), grid, blk, 0, st, g);
   return kd_slab_reduce_launch(g.slab, nsplit, (int64_t)g.N * g.K, dW, st);
 }
 
@@ -392,9 +396,12 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
              X, ldx, esc, esh, emean, einv, epi_act, partial, (int)M, K, N};
   const int64_t nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   hipStream_t st = (hipStream_t)stream;
-  if (epi == 0) hipLaunchKernelGGL(pw_gemm_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, g);
-  else if (epi == 1) hipLaunchKernelGGL(pw_gemm_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, g);
-  else hipLaunchKernelGGL(pw_gemm_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, g);
+  const dim3 grid((unsigned)nblk), blk(256);
+#define KD_GEMM_CASE(P_, E_) if (pro == P_ && epi == E_) hipLaunchKernelGGL((pw_gemm_kernel<P_, E_>), grid, blk, 0, st, g)
+  KD_GEMM_CASE(0, 0); KD_GEMM_CASE(0, 1); KD_GEMM_CASE(0, 2);
+  KD_GEMM_CASE(1, 0); KD_GEMM_CASE(1, 1); KD_GEMM_CASE(1, 2);
+  KD_GEMM_CASE(2, 0); KD_GEMM_CASE(2, 1); KD_GEMM_CASE(2, 2);
+#undef KD_GEMM_CASE
   return kd_check_launch("kd_pwconv_gemm");
 }
 
