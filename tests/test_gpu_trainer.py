@@ -1,0 +1,70 @@
+"""GPU tests of the drop-in training layer: Trainer (CE) and KDTrainer on synthetic PandaSet-shaped
+batches -- loop runs, loss goes down, checkpoint dictionary keeps the reference's keys
+(trainer.py:116-142) and round-trips, history JSON layout (trainer.py:144-152)."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _loaders(n=8, bs=4):
+    from torch.utils.data import DataLoader
+    from src.data_loading.pandaset_dataset import SyntheticPandaSet
+    ds = SyntheticPandaSet(n_frames=n, num_points=1024, image_size=64, bev_size=16, seed=3, pad_tail=64)
+    return DataLoader(ds, batch_size=bs, shuffle=False), DataLoader(ds, batch_size=bs, shuffle=False)
+
+
+def _model(fusion, oc):
+    from _gpu_util import build_product
+    torch.manual_seed(0)
+    return build_product(fusion, 16)
+
+
+def test_trainer_ce_runs_and_checkpoints(tmp_path):
+    from src.training.trainer import Trainer
+    tl, vl = _loaders()
+    model = _model("weighted", 128)
+    tr = Trainer(model, tl, vl, torch.device("cuda"), lr=1e-3, weight_decay=1e-3, save_dir=str(tmp_path),
+                 class_weights=[0.4, 3.5], num_epochs=3)
+    l0, m0 = tr.train_epoch()
+    for _ in range(4):
+        l1, m1 = tr.train_epoch()
+    assert l1 < l0, (l0, l1)
+    vloss, vm = tr.validate()
+    assert 0.0 <= vm["miou"] <= 1.0 and len(vm["class_iou"]) == 2
+    tr.update_history(l1, m1["miou"], vloss, vm["miou"], 1e-3)
+    hist = json.load(open(os.path.join(tmp_path, "training_history.json")))
+    assert list(hist) == ["train_loss", "train_miou", "val_loss", "val_miou", "lr"]
+    tr.save_checkpoint(0, vm["miou"], is_best=True)
+    ck = torch.load(os.path.join(tmp_path, "best.pth"), map_location="cpu")
+    assert set(ck) == {"epoch", "model_state", "optimizer_state", "scheduler_state", "val_miou"}
+    st = ck["optimizer_state"]["state"]
+    assert set(st[0]) == {"step", "exp_avg", "exp_avg_sq"}            # torch.optim.AdamW layout
+    # resume into a fresh trainer: parameters, moments and step count come back
+    model2 = _model("weighted", 128)
+    tr2 = Trainer(model2, tl, vl, torch.device("cuda"), save_dir=str(tmp_path), class_weights=[0.4, 3.5], num_epochs=3)
+    assert tr2.load_checkpoint(os.path.join(tmp_path, "best.pth")) == 1
+    for (n1, p1), (n2, p2) in zip(model.named_parameters(), model2.named_parameters()):
+        assert torch.equal(p1, p2), n1
+    assert torch.equal(tr.optimizer.exp_avg, tr2.optimizer.exp_avg) and tr2.optimizer._step == tr.optimizer._step
+    a, _ = tr.train_epoch()
+    b, _ = tr2.train_epoch()
+    assert abs(a - b) < 1e-5                                           # identical continuation
+
+
+def test_kd_trainer_runs(tmp_path):
+    from src.training.trainer import KDTrainer
+    tl, vl = _loaders()
+    student, teacher = _model("weighted", 128), _model("concat", 256)
+    tr = KDTrainer(student, teacher, tl, vl, torch.device("cuda"), T=4.0, alpha=1.0, beta=1.0, lr=1e-3,
+                   weight_decay=1e-3, save_dir=str(tmp_path), class_weights=[0.4, 3.5], num_epochs=2)
+    before = [p.detach().clone() for p in teacher.parameters()]
+    l0, _ = tr.train_epoch()
+    for _ in range(3):
+        l1, _ = tr.train_epoch()
+    assert l1 < l0
+    assert all(torch.equal(a, b) for a, b in zip(before, teacher.parameters()))   # the teacher is frozen
+    assert not teacher.training and student.training
