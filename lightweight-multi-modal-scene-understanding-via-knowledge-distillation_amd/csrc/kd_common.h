@@ -43,17 +43,20 @@ static inline bool kd_aligned16(const void* p) { return (reinterpret_cast<uintpt
 // tie test all call this, so a recomputed value is bit-identical to the one used in the forward.
 __device__ __forceinline__ float kd_affine(float raw, float sc, float sh) { return fmaf(raw, sc, sh); }
 
+// Activations are a clamp to [lo, hi] with bounds SELECTED from the activation id (none: -inf..inf,
+// ReLU: 0..inf, ReLU6: 0..6).  No branches: a runtime `if (act == ...)` around every element makes
+// hipcc split the surrounding loads into one basic block each and drain the memory queue per load.
+__device__ __forceinline__ float kd_act_lo(int act) { return act == KD_ACT_NONE ? -INFINITY : 0.f; }
+__device__ __forceinline__ float kd_act_hi(int act) { return act == KD_ACT_RELU6 ? 6.f : INFINITY; }
 __device__ __forceinline__ float kd_act(float z, int act) {
-  if (act == KD_ACT_RELU) return z > 0.f ? z : 0.f;
-  if (act == KD_ACT_RELU6) return z > 0.f ? (z < 6.f ? z : 6.f) : 0.f;
-  return z;
+  const float lo = kd_act_lo(act), hi = kd_act_hi(act);
+  z = z > lo ? z : lo;
+  return z < hi ? z : hi;
 }
 // derivative mask of kd_act at pre-activation z (ATen threshold_backward / hardtanh_backward:
 // strict inequalities on both sides)
 __device__ __forceinline__ float kd_act_mask(float z, int act) {
-  if (act == KD_ACT_RELU) return z > 0.f ? 1.f : 0.f;
-  if (act == KD_ACT_RELU6) return (z > 0.f && z < 6.f) ? 1.f : 0.f;
-  return 1.f;
+  return (z > kd_act_lo(act) && z < kd_act_hi(act)) ? 1.f : 0.f;
 }
 
 __device__ __forceinline__ float4 kd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

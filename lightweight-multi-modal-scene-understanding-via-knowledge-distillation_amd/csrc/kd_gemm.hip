@@ -33,7 +33,7 @@ struct GemmArgs {
 };
 
 template <int PRO, int EPI>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void pw_gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 128 * LDSLD];
   float* As = smem;
   float* Bs = smem + 128 * LDSLD;
@@ -53,49 +53,64 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[4], rb[4];
-  auto load_tiles = [&](int kt) {
-    const int k0 = kt * BK;
+  // Loads are BRANCH-FREE: out-of-range rows / columns / k read a clamped (valid) address and are
+  // zeroed by a select in `transform`, which runs only when the tile is about to be written to LDS.
+  // That keeps all 8..17 loads of a tile in ONE basic block, issued back to back, in flight under
+  // the MFMAs of the previous tile.  Per-channel coefficients depend only on (k0, tid & 7).
+  float4 ra[4], rb[4], rx[PRO == 2 ? 4 : 1], co[PRO == 2 ? 5 : 2];
+  const int c4 = tid & 7;
+  auto issue_loads = [&](int kt) {
+    int gk = kt * BK + c4 * 4;
+    gk = gk < g.K ? gk : g.K - 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx >> 3, c4 = idx & 7;
-      const int gk = k0 + c4 * 4;
-      const int64_t gm = m0 + row;
-      float4 va = kd_zero4();
-      if (gm < g.M && gk < g.K) {
-        va = kd_ld4(g.A + gm * g.lda + gk);
-        if (PRO == 1) {
-          va = kd_affine_act4(va, kd_ld4(g.p0 + gk), kd_ld4(g.p1 + gk), g.pro_act);
-        } else if (PRO == 2) {
-          const float4 x = kd_ld4(g.A2 + gm * g.lda2 + gk);
-          const float4 al = kd_ld4(g.p0 + gk), be = kd_ld4(g.p1 + gk), ga = kd_ld4(g.p2 + gk);
-          float4 sc = kd_zero4(), sh = kd_zero4();
-          if (g.pro_act != KD_ACT_NONE) { sc = kd_ld4(g.p3 + gk); sh = kd_ld4(g.p4 + gk); }
-          va.x = kd_bwd_operand(va.x, x.x, al.x, be.x, ga.x, sc.x, sh.x, g.pro_act);
-          va.y = kd_bwd_operand(va.y, x.y, al.y, be.y, ga.y, sc.y, sh.y, g.pro_act);
-          va.z = kd_bwd_operand(va.z, x.z, al.z, be.z, ga.z, sc.z, sh.z, g.pro_act);
-          va.w = kd_bwd_operand(va.w, x.w, al.w, be.w, ga.w, sc.w, sh.w, g.pro_act);
-        }
+      const int row = (tid >> 3) + 32 * i;
+      int64_t gm = m0 + row;
+      gm = gm < g.M ? gm : (int64_t)g.M - 1;
+      ra[i] = kd_ld4(g.A + gm * g.lda + gk);
+      if (PRO == 2) rx[i] = kd_ld4(g.A2 + gm * g.lda2 + gk);
+      int gn = n0 + row;
+      gn = gn < g.N ? gn : g.N - 1;
+      rb[i] = kd_ld4(g.W + (int64_t)gn * g.K + gk);
+    }
+    if (PRO >= 1) { co[0] = kd_ld4(g.p0 + gk); co[1] = kd_ld4(g.p1 + gk); }
+    if (PRO == 2) { co[2] = kd_ld4(g.p2 + gk); co[3] = kd_ld4(g.p3 + gk); co[4] = kd_ld4(g.p4 + gk); }
+  };
+  auto transform = [&](int kt) {
+    const bool kok = kt * BK + c4 * 4 < g.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      float4 va = ra[i];
+      if (PRO == 1) {
+        va = kd_affine_act4(va, co[0], co[1], g.pro_act);
+      } else if (PRO == 2) {
+        const float4 x = rx[i];
+        va.x = kd_bwd_operand(va.x, x.x, co[0].x, co[1].x, co[2].x, co[3].x, co[4].x, g.pro_act);
+        va.y = kd_bwd_operand(va.y, x.y, co[0].y, co[1].y, co[2].y, co[3].y, co[4].y, g.pro_act);
+        va.z = kd_bwd_operand(va.z, x.z, co[0].z, co[1].z, co[2].z, co[3].z, co[4].z, g.pro_act);
+        va.w = kd_bwd_operand(va.w, x.w, co[0].w, co[1].w, co[2].w, co[3].w, co[4].w, g.pro_act);
       }
-      ra[i] = va;
-      const int gn = n0 + row;
-      rb[i] = (gn < g.N && gk < g.K) ? kd_ld4(g.W + (int64_t)gn * g.K + gk) : kd_zero4();
+      const bool aok = kok && (m0 + row < g.M);
+      ra[i] = make_float4(aok ? va.x : 0.f, aok ? va.y : 0.f, aok ? va.z : 0.f, aok ? va.w : 0.f);
+      const bool bok = kok && (n0 + row < g.N);
+      const float4 vb = rb[i];
+      rb[i] = make_float4(bok ? vb.x : 0.f, bok ? vb.y : 0.f, bok ? vb.z : 0.f, bok ? vb.w : 0.f);
     }
   };
 
-  load_tiles(0);
+  issue_loads(0);
   for (int kt = 0; kt < nk; ++kt) {
+    transform(kt);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx >> 3, c4 = idx & 7;
+      const int row = (tid >> 3) + 32 * i;
       kd_st4(As + row * LDSLD + c4 * 4, ra[i]);
       kd_st4(Bs + row * LDSLD + c4 * 4, rb[i]);
     }
     __syncthreads();
-    if (kt + 1 < nk) load_tiles(kt + 1);   // next tile's HBM loads fly under this tile's MFMAs
+    if (kt + 1 < nk) issue_loads(kt + 1);  // next tile's HBM loads fly under this tile's MFMAs
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       f32x4 a[2], b[2];
@@ -120,8 +135,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs g) {
   // loads are whole 512-byte rows (float4 per lane) instead of 4-byte column-strided accesses.
   constexpr int TLD = 132;
   float* T = smem;                                   // [64][TLD] staging (33.8 KB of the 36.9 KB)
-  const int c4 = tid & 31, rg = tid >> 5;            // this thread's 4 columns / row group
-  const int col = n0 + c4 * 4;
+  const int c4e = tid & 31, rg = tid >> 5;           // this thread's 4 columns / row group
+  const int col = n0 + c4e * 4;
   const bool cok = col < g.N;
   float4 bias4 = kd_zero4(), esc = kd_zero4(), esh = kd_zero4(), emean = kd_zero4(), einv = kd_zero4();
   if (cok) {
@@ -143,7 +158,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs g) {
       const int rr = rg + 8 * i;
       const int64_t row = m0 + (rr >> 5) * 64 + h * 32 + (rr & 31);
       if (cok && row < g.M) {
-        float4 v = kd_ld4(T + rr * TLD + c4 * 4);
+        float4 v = kd_ld4(T + rr * TLD + c4e * 4);
         v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
         if (g.addend) {
           const float4 ad = kd_ld4(g.addend + row * g.ldadd + col);
@@ -171,8 +186,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs g) {
   if (EPI != 0) {
     __syncthreads();
     float* red = smem;                               // [8 row groups][2 stats][128 columns]
-    kd_st4(red + (rg * 2 + 0) * 128 + c4 * 4, s1);
-    kd_st4(red + (rg * 2 + 1) * 128 + c4 * 4, s2);
+    kd_st4(red + (rg * 2 + 0) * 128 + c4e * 4, s1);
+    kd_st4(red + (rg * 2 + 1) * 128 + c4e * 4, s2);
     __syncthreads();
     const int st = tid >> 7, c = tid & 127;          // 256 threads = 2 stats x 128 columns
     if (n0 + c < g.N) {
@@ -226,46 +241,60 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 rd[DF4], ra[AF4];
+  // Branch-free loads (clamped addresses, zero-select in `transform` right before the LDS store), so
+  // a chunk's loads sit in one basic block and stay in flight under the previous chunk's MFMAs.
+  // A thread's columns are fixed (256 % (TN/4) == 0), so its coefficient vectors are loaded once.
+  const int dc4 = tid % (TN / 4), ac4 = tid % (TK / 4);
+  const int gn = n0 + dc4 * 4, gk = k0 + ac4 * 4;
+  const bool nok = gn < g.N, kok = gk < g.K;
+  const int gnc = nok ? gn : g.N - 4, gkc = kok ? gk : g.K - 4;
+  float4 cd[DMODE == 2 ? 5 : 1], ca[AMODE == 1 ? 2 : 1], rx[DMODE == 2 ? DF4 : 1];
+  if (DMODE == 2) {
+    cd[0] = kd_ld4(g.al + gnc); cd[1] = kd_ld4(g.be + gnc); cd[2] = kd_ld4(g.ga + gnc);
+    cd[3] = kd_ld4(g.msc + gnc); cd[4] = kd_ld4(g.msh + gnc);
+  }
+  if (AMODE == 1) { ca[0] = kd_ld4(g.asc + gkc); ca[1] = kd_ld4(g.ash + gkc); }
   auto load_chunk = [&](int64_t mc) {
 #pragma unroll
     for (int i = 0; i < DF4; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx / (TN / 4), c4 = idx % (TN / 4);
-      const int64_t gm = mc + row;
-      const int gn = n0 + c4 * 4;
-      float4 v = kd_zero4();
-      if (gm < mend && gn < g.N) {
-        v = kd_ld4(g.D + gm * g.ldd + gn);
-        if (DMODE == 2) {
-          const float4 x = kd_ld4(g.X + gm * g.ldx + gn);
-          const float4 al = kd_ld4(g.al + gn), be = kd_ld4(g.be + gn), ga = kd_ld4(g.ga + gn);
-          float4 sc = kd_zero4(), sh = kd_zero4();
-          if (g.d_act != KD_ACT_NONE) { sc = kd_ld4(g.msc + gn); sh = kd_ld4(g.msh + gn); }
-          v.x = kd_bwd_operand(v.x, x.x, al.x, be.x, ga.x, sc.x, sh.x, g.d_act);
-          v.y = kd_bwd_operand(v.y, x.y, al.y, be.y, ga.y, sc.y, sh.y, g.d_act);
-          v.z = kd_bwd_operand(v.z, x.z, al.z, be.z, ga.z, sc.z, sh.z, g.d_act);
-          v.w = kd_bwd_operand(v.w, x.w, al.w, be.w, ga.w, sc.w, sh.w, g.d_act);
-        }
-      }
-      rd[i] = v;
+      int64_t gm = mc + (tid + 256 * i) / (TN / 4);
+      gm = gm < mend ? gm : mend - 1;
+      rd[i] = kd_ld4(g.D + gm * g.ldd + gnc);
+      if (DMODE == 2) rx[i] = kd_ld4(g.X + gm * g.ldx + gnc);
     }
 #pragma unroll
     for (int i = 0; i < AF4; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx / (TK / 4), c4 = idx % (TK / 4);
-      const int64_t gm = mc + row;
-      const int gk = k0 + c4 * 4;
-      float4 v = kd_zero4();
-      if (gm < mend && gk < g.K) {
-        v = kd_ld4(g.A + gm * g.lda + gk);
-        if (AMODE == 1) v = kd_affine_act4(v, kd_ld4(g.asc + gk), kd_ld4(g.ash + gk), g.a_act);
+      int64_t gm = mc + (tid + 256 * i) / (TK / 4);
+      gm = gm < mend ? gm : mend - 1;
+      ra[i] = kd_ld4(g.A + gm * g.lda + gkc);
+    }
+  };
+  auto transform = [&](int64_t mc) {
+#pragma unroll
+    for (int i = 0; i < DF4; ++i) {
+      float4 v = rd[i];
+      if (DMODE == 2) {
+        const float4 x = rx[i];
+        v.x = kd_bwd_operand(v.x, x.x, cd[0].x, cd[1].x, cd[2].x, cd[3].x, cd[4].x, g.d_act);
+        v.y = kd_bwd_operand(v.y, x.y, cd[0].y, cd[1].y, cd[2].y, cd[3].y, cd[4].y, g.d_act);
+        v.z = kd_bwd_operand(v.z, x.z, cd[0].z, cd[1].z, cd[2].z, cd[3].z, cd[4].z, g.d_act);
+        v.w = kd_bwd_operand(v.w, x.w, cd[0].w, cd[1].w, cd[2].w, cd[3].w, cd[4].w, g.d_act);
       }
-      ra[i] = v;
+      const bool ok = nok && (mc + (tid + 256 * i) / (TN / 4) < mend);
+      rd[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < AF4; ++i) {
+      float4 v = ra[i];
+      if (AMODE == 1) v = kd_affine_act4(v, ca[0], ca[1], g.a_act);
+      const bool ok = kok && (mc + (tid + 256 * i) / (TK / 4) < mend);
+      ra[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     }
   };
 
   if (mbeg < mend) load_chunk(mbeg);
   for (int64_t mc = mbeg; mc < mend; mc += CH) {
+    transform(mc);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < DF4; ++i) {
@@ -392,6 +421,8 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
   }
   if (epi != 0) KD_REQUIRE(partial, KD_ERR_ARG, "kd_pwconv_gemm: stats epilogue needs a partial slab");
   if (epi == 2) KD_REQUIRE(X && esc && esh && emean && einv, KD_ERR_ARG, "kd_pwconv_gemm: EPI2 needs X, sc, sh, mean, invstd");
+  if (pro == 2 && !p3) { p3 = p0; p4 = p0; }          // mask disabled (act none): any valid vector will do
+  KD_REQUIRE(K >= 4, KD_ERR_SHAPE, "kd_pwconv_gemm: K must be >= 4");
   GemmArgs g{A, lda, A2, lda2, p0, p1, p2, p3, p4, pro, pro_act, W, bias, C, ldc, addend, ldadd,
              X, ldx, esc, esh, emean, einv, epi_act, partial, (int)M, K, N};
   const int64_t nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -424,6 +455,7 @@ int kd_pwconv_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, in
   if (d_mode == 2 && d_act != KD_ACT_NONE) KD_REQUIRE(msc && msh, KD_ERR_ARG, "kd_pwconv_wgrad: mask needs sc/sh");
   if (a_mode == 1) KD_REQUIRE(asc && ash, KD_ERR_ARG, "kd_pwconv_wgrad: a_mode 1 needs sc/sh");
   KD_REQUIRE(M < (int64_t)1 << 31, KD_ERR_SHAPE, "kd_pwconv_wgrad: M too large");
+  if (d_mode == 2 && !msc) { msc = al; msh = al; }       // mask disabled (act none): any valid vector will do
   WgradArgs g{D, ldd, X, ldx, al, be, ga, msc, msh, d_mode, d_act, A, lda, asc, ash, a_mode, a_act, (float*)ws,
               (int)M, N, K, 0};
   hipStream_t st = (hipStream_t)stream;
