@@ -32,17 +32,22 @@ struct GemmArgs {
   int M, K, N;
 };
 
-template <int PRO, int EPI>
+// Tile shape: WM x WN waves of 64x64 each (WM*WN == 4): 128x128 for wide outputs, 256x64 when the
+// last (or only) column tile would be at most 64 wide (N = 32, 64, 192, ...) so no MFMA work is
+// wasted on padding columns.
+template <int PRO, int EPI, int WM, int WN>
 __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void pw_gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 128 * LDSLD];
+  constexpr int BMt = 64 * WM, BNt = 64 * WN;
+  constexpr int AF = BMt / 32, BF = BNt / 32;          // float4 loads per thread per K-tile
+  __shared__ __attribute__((aligned(16))) float smem[(BMt + BNt) * LDSLD];
   float* As = smem;
-  float* Bs = smem + 128 * LDSLD;
+  float* Bs = smem + BMt * LDSLD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int nct = (g.N + BN - 1) / BN;
+  const int wr = wave / WN, wc = wave % WN;
+  const int nct = (g.N + BNt - 1) / BNt;
   const int rowblk = blockIdx.x / nct, ct = blockIdx.x % nct;
-  const int64_t m0 = (int64_t)rowblk * BM;
-  const int n0 = ct * BN;
+  const int64_t m0 = (int64_t)rowblk * BMt;
+  const int n0 = ct * BNt;
   const int nk = (g.K + BK - 1) / BK;
 
   f32x16 acc[2][2];
@@ -55,21 +60,23 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void pw_gemm_kernel(GemmArgs
 
   // Loads are BRANCH-FREE: out-of-range rows / columns / k read a clamped (valid) address and are
   // zeroed by a select in `transform`, which runs only when the tile is about to be written to LDS.
-  // That keeps all 8..17 loads of a tile in ONE basic block, issued back to back, in flight under
-  // the MFMAs of the previous tile.  Per-channel coefficients depend only on (k0, tid & 7).
-  float4 ra[4], rb[4], rx[PRO == 2 ? 4 : 1], co[PRO == 2 ? 5 : 2];
+  // That keeps all loads of a tile in ONE basic block, issued back to back, in flight under the
+  // MFMAs of the previous tile.  Per-channel coefficients depend only on (k0, tid & 7).
+  float4 ra[AF], rb[BF], rx[PRO == 2 ? AF : 1], co[PRO == 2 ? 5 : 2];
   const int c4 = tid & 7;
   auto issue_loads = [&](int kt) {
     int gk = kt * BK + c4 * 4;
     gk = gk < g.K ? gk : g.K - 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (tid >> 3) + 32 * i;
-      int64_t gm = m0 + row;
+    for (int i = 0; i < AF; ++i) {
+      int64_t gm = m0 + (tid >> 3) + 32 * i;
       gm = gm < g.M ? gm : (int64_t)g.M - 1;
       ra[i] = kd_ld4(g.A + gm * g.lda + gk);
       if (PRO == 2) rx[i] = kd_ld4(g.A2 + gm * g.lda2 + gk);
-      int gn = n0 + row;
+    }
+#pragma unroll
+    for (int i = 0; i < BF; ++i) {
+      int gn = n0 + (tid >> 3) + 32 * i;
       gn = gn < g.N ? gn : g.N - 1;
       rb[i] = kd_ld4(g.W + (int64_t)gn * g.K + gk);
     }
@@ -79,8 +86,7 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void pw_gemm_kernel(GemmArgs
   auto transform = [&](int kt) {
     const bool kok = kt * BK + c4 * 4 < g.K;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (tid >> 3) + 32 * i;
+    for (int i = 0; i < AF; ++i) {
       float4 va = ra[i];
       if (PRO == 1) {
         va = kd_affine_act4(va, co[0], co[1], g.pro_act);
@@ -91,9 +97,12 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void pw_gemm_kernel(GemmArgs
         va.z = kd_bwd_operand(va.z, x.z, co[0].z, co[1].z, co[2].z, co[3].z, co[4].z, g.pro_act);
         va.w = kd_bwd_operand(va.w, x.w, co[0].w, co[1].w, co[2].w, co[3].w, co[4].w, g.pro_act);
       }
-      const bool aok = kok && (m0 + row < g.M);
+      const bool aok = kok && (m0 + (tid >> 3) + 32 * i < g.M);
       ra[i] = make_float4(aok ? va.x : 0.f, aok ? va.y : 0.f, aok ? va.z : 0.f, aok ? va.w : 0.f);
-      const bool bok = kok && (n0 + row < g.N);
+    }
+#pragma unroll
+    for (int i = 0; i < BF; ++i) {
+      const bool bok = kok && (n0 + (tid >> 3) + 32 * i < g.N);
       const float4 vb = rb[i];
       rb[i] = make_float4(bok ? vb.x : 0.f, bok ? vb.y : 0.f, bok ? vb.z : 0.f, bok ? vb.w : 0.f);
     }
@@ -104,11 +113,9 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void pw_gemm_kernel(GemmArgs
     transform(kt);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (tid >> 3) + 32 * i;
-      kd_st4(As + row * LDSLD + c4 * 4, ra[i]);
-      kd_st4(Bs + row * LDSLD + c4 * 4, rb[i]);
-    }
+    for (int i = 0; i < AF; ++i) kd_st4(As + ((tid >> 3) + 32 * i) * LDSLD + c4 * 4, ra[i]);
+#pragma unroll
+    for (int i = 0; i < BF; ++i) kd_st4(Bs + ((tid >> 3) + 32 * i) * LDSLD + c4 * 4, rb[i]);
     __syncthreads();
     if (kt + 1 < nk) issue_loads(kt + 1);  // next tile's HBM loads fly under this tile's MFMAs
 #pragma unroll
@@ -131,11 +138,14 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void pw_gemm_kernel(GemmArgs
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
-  // The accumulator tile goes through LDS in two 64-row halves so that C stores and the X / addend
-  // loads are whole 512-byte rows (float4 per lane) instead of 4-byte column-strided accesses.
-  constexpr int TLD = 132;
-  float* T = smem;                                   // [64][TLD] staging (33.8 KB of the 36.9 KB)
-  const int c4e = tid & 31, rg = tid >> 5;           // this thread's 4 columns / row group
+  // The accumulator tile goes through LDS in two halves (the mi = 0 / 1 row groups of every wave) so
+  // that C stores and the X / addend loads are whole rows (float4 per lane, BNt*4 contiguous bytes)
+  // instead of 4-byte column-strided accesses.
+  constexpr int TLD = BNt + 4;
+  constexpr int CPT = BNt / 4, RG = 256 / CPT;        // column groups, row groups; 8 iterations cover WM*32 rows
+  static_assert(WM * 32 * TLD <= (BMt + BNt) * LDSLD, "epilogue staging must fit the operand LDS");
+  float* T = smem;
+  const int c4e = tid % CPT, rg = tid / CPT;
   const int col = n0 + c4e * 4;
   const bool cok = col < g.N;
   float4 bias4 = kd_zero4(), esc = kd_zero4(), esh = kd_zero4(), emean = kd_zero4(), einv = kd_zero4();
@@ -154,8 +164,8 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void pw_gemm_kernel(GemmArgs
         T[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TLD + wc * 64 + ni * 32 + (lane & 31)] = acc[h][ni][r];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int rr = rg + 8 * i;
+    for (int i = 0; i < (WM * 32) / RG; ++i) {
+      const int rr = rg + RG * i;
       const int64_t row = m0 + (rr >> 5) * 64 + h * 32 + (rr & 31);
       if (cok && row < g.M) {
         float4 v = kd_ld4(T + rr * TLD + c4e * 4);
@@ -185,16 +195,20 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void pw_gemm_kernel(GemmArgs
   }
   if (EPI != 0) {
     __syncthreads();
-    float* red = smem;                               // [8 row groups][2 stats][128 columns]
-    kd_st4(red + (rg * 2 + 0) * 128 + c4e * 4, s1);
-    kd_st4(red + (rg * 2 + 1) * 128 + c4e * 4, s2);
+    float* red = smem;                               // [RG row groups][2 stats][BNt columns]
+    kd_st4(red + (rg * 2 + 0) * BNt + c4e * 4, s1);
+    kd_st4(red + (rg * 2 + 1) * BNt + c4e * 4, s2);
     __syncthreads();
-    const int st = tid >> 7, c = tid & 127;          // 256 threads = 2 stats x 128 columns
-    if (n0 + c < g.N) {
+    // the stats slab has one row per 128 matrix rows (kd_pwconv_stat_rows): a 256-row tile fills
+    // slab row 2*rowblk and zeroes row 2*rowblk+1
+    const int st = tid / BNt, c = tid % BNt;
+    if (tid < 2 * BNt && n0 + c < g.N) {
       float s = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s += red[(k * 2 + st) * 128 + c];
-      g.partial[((int64_t)rowblk * 2 + st) * g.N + n0 + c] = s;
+      for (int k = 0; k < RG; ++k) s += red[(k * 2 + st) * BNt + c];
+      const int64_t srow = (int64_t)rowblk * (BMt / 128);
+      g.partial[(srow * 2 + st) * g.N + n0 + c] = s;
+      if (BMt == 256 && (srow + 1) * 128 < g.M) g.partial[((srow + 1) * 2 + st) * g.N + n0 + c] = 0.f;
     }
   }
 }
@@ -425,13 +439,20 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
   KD_REQUIRE(K >= 4, KD_ERR_SHAPE, "kd_pwconv_gemm: K must be >= 4");
   GemmArgs g{A, lda, A2, lda2, p0, p1, p2, p3, p4, pro, pro_act, W, bias, C, ldc, addend, ldadd,
              X, ldx, esc, esh, emean, einv, epi_act, partial, (int)M, K, N};
-  const int64_t nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)nblk), blk(256);
-#define KD_GEMM_CASE(P_, E_) if (pro == P_ && epi == E_) hipLaunchKernelGGL((pw_gemm_kernel<P_, E_>), grid, blk, 0, st, g)
-  KD_GEMM_CASE(0, 0); KD_GEMM_CASE(0, 1); KD_GEMM_CASE(0, 2);
-  KD_GEMM_CASE(1, 0); KD_GEMM_CASE(1, 1); KD_GEMM_CASE(1, 2);
-  KD_GEMM_CASE(2, 0); KD_GEMM_CASE(2, 1); KD_GEMM_CASE(2, 2);
+  const dim3 blk(256);
+  // 256x64 tiles when the last column tile would be <= 64 wide (N = 32, 64, 192, ...)
+  const bool tall = ((N - 1) % 128) < 64;
+  const int64_t nblk = tall ? ((M + 255) / 256) * ((N + 63) / 64) : ((M + 127) / 128) * ((N + 127) / 128);
+  const dim3 grid((unsigned)nblk);
+#define KD_GEMM_CASE(P_, E_)                                                                       \
+  if (pro == P_ && epi == E_) {                                                                    \
+    if (tall) hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 4, 1>), grid, blk, 0, st, g);             \
+    else hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 2, 2>), grid, blk, 0, st, g);                  \
+  }
+  KD_GEMM_CASE(0, 0) KD_GEMM_CASE(0, 1) KD_GEMM_CASE(0, 2)
+  KD_GEMM_CASE(1, 0) KD_GEMM_CASE(1, 1) KD_GEMM_CASE(1, 2)
+  KD_GEMM_CASE(2, 0) KD_GEMM_CASE(2, 1) KD_GEMM_CASE(2, 2)
 #undef KD_GEMM_CASE
   return kd_check_launch("kd_pwconv_gemm");
 }
