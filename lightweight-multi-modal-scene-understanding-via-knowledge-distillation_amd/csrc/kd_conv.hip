@@ -311,6 +311,221 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(DwBwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sliding-window depthwise kernels.  A work item is a column segment (b, 16-row segment, w); a thread
+// walks down the segment keeping the 3x3 window of ACTIVATED inputs in registers and loading one new
+// input row (3 float4) per output row -- 3 loads and 3 activations per output instead of 9 (and 5
+// instead of 11 in the weight gradient, 6 instead of 18 in the stride-1 data gradient).
+constexpr int DW_SEG = 16;
+
+struct DwRow { float4 l, c, r; };
+
+// activated input row (hi, wi-1..wi+1) of image b, zero outside the image (branch-free)
+__device__ __forceinline__ DwRow dw_load_row(const float* __restrict__ x, bool deferred, float4 sc, float4 sh, int act,
+                                             int b, int hi, int wi, int H, int W, int C, int c0) {
+  const bool hok = hi >= 0 && hi < H;
+  const int hic = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
+  const float* rowp = x + ((int64_t)b * H + hic) * W * C + c0;
+  const bool lok = hok && wi - 1 >= 0, cok = hok, rok = hok && wi + 1 < W;
+  const int wl = wi - 1 < 0 ? 0 : wi - 1, wr_ = wi + 1 >= W ? W - 1 : wi + 1;
+  float4 l = kd_ld4(rowp + (int64_t)wl * C), c = kd_ld4(rowp + (int64_t)wi * C), r = kd_ld4(rowp + (int64_t)wr_ * C);
+  if (deferred) { l = kd_affine_act4(l, sc, sh, act); c = kd_affine_act4(c, sc, sh, act); r = kd_affine_act4(r, sc, sh, act); }
+  DwRow o;
+  o.l = make_float4(lok ? l.x : 0.f, lok ? l.y : 0.f, lok ? l.z : 0.f, lok ? l.w : 0.f);
+  o.c = make_float4(cok ? c.x : 0.f, cok ? c.y : 0.f, cok ? c.z : 0.f, cok ? c.w : 0.f);
+  o.r = make_float4(rok ? r.x : 0.f, rok ? r.y : 0.f, rok ? r.z : 0.f, rok ? r.w : 0.f);
+  return o;
+}
+
+__device__ __forceinline__ void dw_fma_row(float4& acc, const DwRow& r, const float (*w)[9], int kh) {
+  acc.x = fmaf(r.l.x, w[0][kh * 3], fmaf(r.c.x, w[0][kh * 3 + 1], fmaf(r.r.x, w[0][kh * 3 + 2], acc.x)));
+  acc.y = fmaf(r.l.y, w[1][kh * 3], fmaf(r.c.y, w[1][kh * 3 + 1], fmaf(r.r.y, w[1][kh * 3 + 2], acc.y)));
+  acc.z = fmaf(r.l.z, w[2][kh * 3], fmaf(r.c.z, w[2][kh * 3 + 1], fmaf(r.r.z, w[2][kh * 3 + 2], acc.z)));
+  acc.w = fmaf(r.l.w, w[3][kh * 3], fmaf(r.c.w, w[3][kh * 3 + 1], fmaf(r.r.w, w[3][kh * 3 + 2], acc.w)));
+}
+
+__device__ __forceinline__ void dw_block_stats(float* red, float4 s1, float4 s2, float* partial, int C, int groups, int slots) {
+  const int tid = threadIdx.x;
+  kd_st4(red + tid * 4, s1);
+  kd_st4(red + 1024 + tid * 4, s2);
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 256) {
+    const int st = i / C, c = i % C;
+    float s = 0.f;
+    for (int sl = 0; sl < slots; ++sl) s += red[st * 1024 + (sl * groups + c / 4) * 4 + (c & 3)];
+    partial[((int64_t)blockIdx.x * 2 + st) * C + c] = s;
+  }
+}
+
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw_fwd_sw_kernel(DwArgs a) {
+  __shared__ float red[2 * 256 * 4];
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  const bool active = slot < a.slots;
+  const int c0 = gidx * 4;
+  float wreg[4][9];
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4();
+  float4 s1 = kd_zero4(), s2 = kd_zero4();
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wreg[j][t] = a.w[(c0 + j) * 9 + t];
+    const bool deferred = a.sc != nullptr;
+    if (deferred) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
+    const int nseg = (a.Ho + DW_SEG - 1) / DW_SEG;
+    const int64_t items = (int64_t)a.B * nseg * a.Wo;
+    for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+      const int wo = (int)(it % a.Wo), sg = (int)((it / a.Wo) % nseg), b = (int)(it / ((int64_t)a.Wo * nseg));
+      const int h0 = sg * DW_SEG, h1 = h0 + DW_SEG < a.Ho ? h0 + DW_SEG : a.Ho;
+      const int wi = wo * STRIDE;
+      DwRow r0 = dw_load_row(a.x, deferred, sc, sh, a.act, b, h0 * STRIDE - 1, wi, a.H, a.W, a.C, c0), r1, r2;
+      if (STRIDE == 1) r1 = dw_load_row(a.x, deferred, sc, sh, a.act, b, h0, wi, a.H, a.W, a.C, c0);
+      for (int ho = h0; ho < h1; ++ho) {
+        if (STRIDE == 2) r1 = dw_load_row(a.x, deferred, sc, sh, a.act, b, 2 * ho, wi, a.H, a.W, a.C, c0);
+        r2 = dw_load_row(a.x, deferred, sc, sh, a.act, b, ho * STRIDE + 1, wi, a.H, a.W, a.C, c0);
+        float4 acc = kd_zero4();
+        dw_fma_row(acc, r0, wreg, 0);
+        dw_fma_row(acc, r1, wreg, 1);
+        dw_fma_row(acc, r2, wreg, 2);
+        kd_st4(a.y + (((int64_t)b * a.Ho + ho) * a.Wo + wo) * a.C + c0, acc);
+        s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+        s2.x = fmaf(acc.x, acc.x, s2.x); s2.y = fmaf(acc.y, acc.y, s2.y);
+        s2.z = fmaf(acc.z, acc.z, s2.z); s2.w = fmaf(acc.w, acc.w, s2.w);
+        if (STRIDE == 1) { r0 = r1; r1 = r2; } else { r0 = r2; }
+      }
+    }
+  }
+  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
+}
+
+// dyeff row (ho, wo-1..wo+1), zero outside the output image
+__device__ __forceinline__ DwRow dw_load_dy_row(const DwBwdArgs& a, float4 al, float4 be, float4 ga, float4 dsc, float4 dsh,
+                                                int b, int ho, int wo, int c0) {
+  const bool hok = ho >= 0 && ho < a.Ho;
+  const int hoc = ho < 0 ? 0 : (ho >= a.Ho ? a.Ho - 1 : ho);
+  const int wl = wo - 1 < 0 ? 0 : wo - 1, wr_ = wo + 1 >= a.Wo ? a.Wo - 1 : wo + 1;
+  const int64_t base = ((int64_t)b * a.Ho + hoc) * a.Wo;
+  const float4 l = dw_dyeff(a, base + wl, c0, al, be, ga, dsc, dsh), c = dw_dyeff(a, base + wo, c0, al, be, ga, dsc, dsh),
+               r = dw_dyeff(a, base + wr_, c0, al, be, ga, dsc, dsh);
+  const bool lok = hok && wo - 1 >= 0, rok = hok && wo + 1 < a.Wo;
+  DwRow o;
+  o.l = make_float4(lok ? l.x : 0.f, lok ? l.y : 0.f, lok ? l.z : 0.f, lok ? l.w : 0.f);
+  o.c = make_float4(hok ? c.x : 0.f, hok ? c.y : 0.f, hok ? c.z : 0.f, hok ? c.w : 0.f);
+  o.r = make_float4(rok ? r.x : 0.f, rok ? r.y : 0.f, rok ? r.z : 0.f, rok ? r.w : 0.f);
+  return o;
+}
+
+// stride-1 data gradient: gx[hi][wi] = mask * sum_{dh,dw} dy[hi+dh][wi+dw] * w[1-dh][1-dw]
+__global__ __launch_bounds__(256) void dw_bwd_data_sw_kernel(DwBwdArgs a) {
+  __shared__ float red[2 * 256 * 4];
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  const bool active = slot < a.slots;
+  const int c0 = gidx * 4;
+  float4 s1 = kd_zero4(), s2 = kd_zero4();
+  if (active) {
+    float wf[4][9];                     // flipped taps: wf[j][(dh+1)*3 + (dw+1)] = w[j][(1-dh)*3 + (1-dw)]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wf[j][t] = a.w[(c0 + j) * 9 + (8 - t)];
+    float4 al = kd_zero4(), be = kd_zero4(), ga = kd_zero4(), dsc = kd_zero4(), dsh = kd_zero4();
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4(), mean = kd_zero4(), inv = kd_zero4();
+    if (a.al) { al = kd_ld4(a.al + c0); be = kd_ld4(a.be + c0); ga = kd_ld4(a.ga + c0); }
+    if (a.dsc) { dsc = kd_ld4(a.dsc + c0); dsh = kd_ld4(a.dsh + c0); }
+    if (a.sc) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
+    if (a.mean) { mean = kd_ld4(a.mean + c0); inv = kd_ld4(a.invstd + c0); }
+    const int nseg = (a.H + DW_SEG - 1) / DW_SEG;
+    const int64_t items = (int64_t)a.B * nseg * a.W;
+    for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+      const int wi = (int)(it % a.W), sg = (int)((it / a.W) % nseg), b = (int)(it / ((int64_t)a.W * nseg));
+      const int h0 = sg * DW_SEG, h1 = h0 + DW_SEG < a.H ? h0 + DW_SEG : a.H;
+      DwRow r0 = dw_load_dy_row(a, al, be, ga, dsc, dsh, b, h0 - 1, wi, c0);
+      DwRow r1 = dw_load_dy_row(a, al, be, ga, dsc, dsh, b, h0, wi, c0), r2;
+      for (int hi = h0; hi < h1; ++hi) {
+        r2 = dw_load_dy_row(a, al, be, ga, dsc, dsh, b, hi + 1, wi, c0);
+        float4 acc = kd_zero4();
+        dw_fma_row(acc, r0, wf, 0);
+        dw_fma_row(acc, r1, wf, 1);
+        dw_fma_row(acc, r2, wf, 2);
+        const int64_t p = ((int64_t)b * a.H + hi) * a.W + wi;
+        if (a.sc) {
+          const float4 xr = kd_ld4(a.x + p * a.C + c0);
+          acc.x *= kd_act_mask(kd_affine(xr.x, sc.x, sh.x), a.act);
+          acc.y *= kd_act_mask(kd_affine(xr.y, sc.y, sh.y), a.act);
+          acc.z *= kd_act_mask(kd_affine(xr.z, sc.z, sh.z), a.act);
+          acc.w *= kd_act_mask(kd_affine(xr.w, sc.w, sh.w), a.act);
+          s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+          s2.x = fmaf(acc.x, (xr.x - mean.x) * inv.x, s2.x);
+          s2.y = fmaf(acc.y, (xr.y - mean.y) * inv.y, s2.y);
+          s2.z = fmaf(acc.z, (xr.z - mean.z) * inv.z, s2.z);
+          s2.w = fmaf(acc.w, (xr.w - mean.w) * inv.w, s2.w);
+        }
+        kd_st4(a.gx + p * a.C + c0, acc);
+        r0 = r1; r1 = r2;
+      }
+    }
+  }
+  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
+}
+
+// weight gradient with the same input window as the forward
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw_bwd_weight_sw_kernel(DwBwdArgs a) {
+  __shared__ float red[256 * 4];
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  const bool active = slot < a.slots;
+  const int c0 = gidx * 4;
+  float4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = kd_zero4();
+  if (active) {
+    float4 al = kd_zero4(), be = kd_zero4(), ga = kd_zero4(), dsc = kd_zero4(), dsh = kd_zero4();
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4();
+    if (a.al) { al = kd_ld4(a.al + c0); be = kd_ld4(a.be + c0); ga = kd_ld4(a.ga + c0); }
+    if (a.dsc) { dsc = kd_ld4(a.dsc + c0); dsh = kd_ld4(a.dsh + c0); }
+    const bool deferred = a.sc != nullptr;
+    if (deferred) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
+    const int nseg = (a.Ho + DW_SEG - 1) / DW_SEG;
+    const int64_t items = (int64_t)a.B * nseg * a.Wo;
+    for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+      const int wo = (int)(it % a.Wo), sg = (int)((it / a.Wo) % nseg), b = (int)(it / ((int64_t)a.Wo * nseg));
+      const int h0 = sg * DW_SEG, h1 = h0 + DW_SEG < a.Ho ? h0 + DW_SEG : a.Ho;
+      const int wi = wo * STRIDE;
+      DwRow r0 = dw_load_row(a.x, deferred, sc, sh, a.act, b, h0 * STRIDE - 1, wi, a.H, a.W, a.C, c0), r1, r2;
+      if (STRIDE == 1) r1 = dw_load_row(a.x, deferred, sc, sh, a.act, b, h0, wi, a.H, a.W, a.C, c0);
+      for (int ho = h0; ho < h1; ++ho) {
+        if (STRIDE == 2) r1 = dw_load_row(a.x, deferred, sc, sh, a.act, b, 2 * ho, wi, a.H, a.W, a.C, c0);
+        r2 = dw_load_row(a.x, deferred, sc, sh, a.act, b, ho * STRIDE + 1, wi, a.H, a.W, a.C, c0);
+        const float4 d = dw_dyeff(a, ((int64_t)b * a.Ho + ho) * a.Wo + wo, c0, al, be, ga, dsc, dsh);
+#define KD_DW_WG(KH, R)                                                                                     \
+  acc[KH * 3 + 0].x = fmaf(d.x, R.l.x, acc[KH * 3 + 0].x); acc[KH * 3 + 0].y = fmaf(d.y, R.l.y, acc[KH * 3 + 0].y); \
+  acc[KH * 3 + 0].z = fmaf(d.z, R.l.z, acc[KH * 3 + 0].z); acc[KH * 3 + 0].w = fmaf(d.w, R.l.w, acc[KH * 3 + 0].w); \
+  acc[KH * 3 + 1].x = fmaf(d.x, R.c.x, acc[KH * 3 + 1].x); acc[KH * 3 + 1].y = fmaf(d.y, R.c.y, acc[KH * 3 + 1].y); \
+  acc[KH * 3 + 1].z = fmaf(d.z, R.c.z, acc[KH * 3 + 1].z); acc[KH * 3 + 1].w = fmaf(d.w, R.c.w, acc[KH * 3 + 1].w); \
+  acc[KH * 3 + 2].x = fmaf(d.x, R.r.x, acc[KH * 3 + 2].x); acc[KH * 3 + 2].y = fmaf(d.y, R.r.y, acc[KH * 3 + 2].y); \
+  acc[KH * 3 + 2].z = fmaf(d.z, R.r.z, acc[KH * 3 + 2].z); acc[KH * 3 + 2].w = fmaf(d.w, R.r.w, acc[KH * 3 + 2].w);
+        KD_DW_WG(0, r0) KD_DW_WG(1, r1) KD_DW_WG(2, r2)
+#undef KD_DW_WG
+        if (STRIDE == 1) { r0 = r1; r1 = r2; } else { r0 = r2; }
+      }
+    }
+  }
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+    kd_st4(red + tid * 4, acc[t]);
+    __syncthreads();
+    for (int c = tid; c < a.C; c += 256) {
+      float s = 0.f;
+      for (int sl = 0; sl < a.slots; ++sl) s += red[(sl * a.groups + c / 4) * 4 + (c & 3)];
+      a.wslab[(int64_t)blockIdx.x * a.C * 9 + c * 9 + t] = s;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -352,7 +567,8 @@ int kd_dwconv3x3_fwd(const float* x, const float* sc, const float* sh, int act, 
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const KdCgLayout l = kd_cg_layout((int64_t)B * Ho * Wo, C);
   DwArgs a{x, sc, sh, act, w, y, partial, B, H, W, C, Ho, Wo, stride, l.groups, l.slots};
-  hipLaunchKernelGGL(dw_fwd_kernel, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (stride == 1) hipLaunchKernelGGL(dw_fwd_sw_kernel<1>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(dw_fwd_sw_kernel<2>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   return kd_check_launch("kd_dwconv3x3_fwd");
 }
 
@@ -376,7 +592,8 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
     const KdCgLayout l = kd_cg_layout((int64_t)B * H * W, C);
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,
                 nullptr, B, H, W, C, Ho, Wo, stride, l.groups, l.slots};
-    hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(l.grid), dim3(256), 0, st, a);
+    if (stride == 1) hipLaunchKernelGGL(dw_bwd_data_sw_kernel, dim3(l.grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(data)");
     if (rc) return rc;
   }
@@ -385,7 +602,8 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
     KD_REQUIRE(ws && ws_bytes >= (size_t)l.grid * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, nullptr, nullptr, (float*)ws,
                 B, H, W, C, Ho, Wo, stride, l.groups, l.slots};
-    hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(l.grid), dim3(256), 0, st, a);
+    if (stride == 1) hipLaunchKernelGGL(dw_bwd_weight_sw_kernel<1>, dim3(l.grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dw_bwd_weight_sw_kernel<2>, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(weight)");
     if (rc) return rc;
     return kd_slab_reduce_launch((const float*)ws, l.grid, (int64_t)C * 9, dw, st);
