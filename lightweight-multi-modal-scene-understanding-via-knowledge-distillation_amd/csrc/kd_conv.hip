@@ -471,6 +471,71 @@ __global__ __launch_bounds__(256) void dw_bwd_data_sw_kernel(DwBwdArgs a) {
   if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
 }
 
+// stride-2 data gradient, branch-free: input pixel (hi, wi) receives from at most 2 x 2 output pixels:
+//   row candidates  a: kh = (hi+1)&1, ho = (hi+1-kh)/2      b (only if kh_a == 0): kh = 2, ho = ho_a - 1
+// (same along w).  All four dyeff values are loaded from clamped addresses and masked by selects.
+__global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(DwBwdArgs a) {
+  __shared__ float red[2 * 256 * 4];
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  const bool active = slot < a.slots;
+  const int c0 = gidx * 4;
+  float4 s1 = kd_zero4(), s2 = kd_zero4();
+  if (active) {
+    float wreg[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wreg[j][t] = a.w[(c0 + j) * 9 + t];
+    float4 al = kd_zero4(), be = kd_zero4(), ga = kd_zero4(), dsc = kd_zero4(), dsh = kd_zero4();
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4(), mean = kd_zero4(), inv = kd_zero4();
+    if (a.al) { al = kd_ld4(a.al + c0); be = kd_ld4(a.be + c0); ga = kd_ld4(a.ga + c0); }
+    if (a.dsc) { dsc = kd_ld4(a.dsc + c0); dsh = kd_ld4(a.dsh + c0); }
+    if (a.sc) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
+    if (a.mean) { mean = kd_ld4(a.mean + c0); inv = kd_ld4(a.invstd + c0); }
+    const int64_t npix = (int64_t)a.B * a.H * a.W;
+    for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < npix; p += (int64_t)gridDim.x * a.slots) {
+      const int wi = (int)(p % a.W), hi = (int)((p / a.W) % a.H), b = (int)(p / ((int64_t)a.W * a.H));
+      const int kha = (hi + 1) & 1, hoa = (hi + 1 - kha) >> 1, hob = hoa - 1;
+      const int kwa = (wi + 1) & 1, woa = (wi + 1 - kwa) >> 1, wob = woa - 1;
+      const bool ha = hoa < a.Ho, hb = kha == 0 && hob >= 0;
+      const bool wa = woa < a.Wo, wb = kwa == 0 && wob >= 0;
+      const int hoac = ha ? hoa : a.Ho - 1, hobc = hob >= 0 ? hob : 0;
+      const int woac = wa ? woa : a.Wo - 1, wobc = wob >= 0 ? wob : 0;
+      const int64_t ba = ((int64_t)b * a.Ho + hoac) * a.Wo, bb = ((int64_t)b * a.Ho + hobc) * a.Wo;
+      const float4 daa = dw_dyeff(a, ba + woac, c0, al, be, ga, dsc, dsh), dab = dw_dyeff(a, ba + wobc, c0, al, be, ga, dsc, dsh);
+      const float4 dba = dw_dyeff(a, bb + woac, c0, al, be, ga, dsc, dsh), dbb = dw_dyeff(a, bb + wobc, c0, al, be, ga, dsc, dsh);
+      const float faa = (ha && wa) ? 1.f : 0.f, fab = (ha && wb) ? 1.f : 0.f, fba = (hb && wa) ? 1.f : 0.f, fbb = (hb && wb) ? 1.f : 0.f;
+      float4 acc;
+      float* accp = reinterpret_cast<float*>(&acc);
+      const float* paa = reinterpret_cast<const float*>(&daa); const float* pab = reinterpret_cast<const float*>(&dab);
+      const float* pba = reinterpret_cast<const float*>(&dba); const float* pbb = reinterpret_cast<const float*>(&dbb);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // taps: (kha, kwa), (kha, 2), (2, kwa), (2, 2) with kha, kwa in {0, 1}: selects, no dynamic indexing
+        const float w_a0 = kha ? wreg[j][3] : wreg[j][0], w_a1 = kha ? wreg[j][4] : wreg[j][1], w_a2 = kha ? wreg[j][5] : wreg[j][2];
+        const float waa = kwa ? w_a1 : w_a0, wab = w_a2;
+        const float wba = kwa ? wreg[j][7] : wreg[j][6], wbb = wreg[j][8];
+        accp[j] = faa * paa[j] * waa + fab * pab[j] * wab + fba * pba[j] * wba + fbb * pbb[j] * wbb;
+      }
+      if (a.sc) {
+        const float4 xr = kd_ld4(a.x + p * a.C + c0);
+        acc.x *= kd_act_mask(kd_affine(xr.x, sc.x, sh.x), a.act);
+        acc.y *= kd_act_mask(kd_affine(xr.y, sc.y, sh.y), a.act);
+        acc.z *= kd_act_mask(kd_affine(xr.z, sc.z, sh.z), a.act);
+        acc.w *= kd_act_mask(kd_affine(xr.w, sc.w, sh.w), a.act);
+        s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+        s2.x = fmaf(acc.x, (xr.x - mean.x) * inv.x, s2.x);
+        s2.y = fmaf(acc.y, (xr.y - mean.y) * inv.y, s2.y);
+        s2.z = fmaf(acc.z, (xr.z - mean.z) * inv.z, s2.z);
+        s2.w = fmaf(acc.w, (xr.w - mean.w) * inv.w, s2.w);
+      }
+      kd_st4(a.gx + p * a.C + c0, acc);
+    }
+  }
+  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
+}
+
 // weight gradient with the same input window as the forward
 template <int STRIDE>
 __global__ __launch_bounds__(256) void dw_bwd_weight_sw_kernel(DwBwdArgs a) {
@@ -593,7 +658,7 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,
                 nullptr, B, H, W, C, Ho, Wo, stride, l.groups, l.slots};
     if (stride == 1) hipLaunchKernelGGL(dw_bwd_data_sw_kernel, dim3(l.grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(l.grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dw_bwd_data_s2_kernel, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(data)");
     if (rc) return rc;
   }
