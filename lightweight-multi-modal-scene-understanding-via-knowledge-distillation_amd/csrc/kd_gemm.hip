@@ -36,7 +36,7 @@ struct GemmArgs {
 // last (or only) column tile would be at most 64 wide (N = 32, 64, 192, ...) so no MFMA work is
 // wasted on padding columns.
 template <int PRO, int EPI, int WM, int WN>
-__global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void pw_gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (PRO == 2 && WM == 4) ? 2 : 3) void pw_gemm_kernel(GemmArgs g) {
   constexpr int BMt = 64 * WM, BNt = 64 * WN;
   constexpr int AF = BMt / 32, BF = BNt / 32;          // float4 loads per thread per K-tile
   __shared__ __attribute__((aligned(16))) float smem[(BMt + BNt) * LDSLD];
@@ -80,11 +80,15 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void pw_gemm_kernel(GemmArgs
       gn = gn < g.N ? gn : g.N - 1;
       rb[i] = kd_ld4(g.W + (int64_t)gn * g.K + gk);
     }
-    if (PRO >= 1) { co[0] = kd_ld4(g.p0 + gk); co[1] = kd_ld4(g.p1 + gk); }
-    if (PRO == 2) { co[2] = kd_ld4(g.p2 + gk); co[3] = kd_ld4(g.p3 + gk); co[4] = kd_ld4(g.p4 + gk); }
+    if (PRO == 1) { co[0] = kd_ld4(g.p0 + gk); co[1] = kd_ld4(g.p1 + gk); }
   };
   auto transform = [&](int kt) {
     const bool kok = kt * BK + c4 * 4 < g.K;
+    if (PRO == 2) {   // 5 coefficient vectors: cache-resident, fetched here so they do not occupy 20 VGPRs under the MFMAs
+      int gk = kt * BK + c4 * 4;
+      gk = gk < g.K ? gk : g.K - 4;
+      co[0] = kd_ld4(g.p0 + gk); co[1] = kd_ld4(g.p1 + gk); co[2] = kd_ld4(g.p2 + gk); co[3] = kd_ld4(g.p3 + gk); co[4] = kd_ld4(g.p4 + gk);
+    }
 #pragma unroll
     for (int i = 0; i < AF; ++i) {
       float4 va = ra[i];
