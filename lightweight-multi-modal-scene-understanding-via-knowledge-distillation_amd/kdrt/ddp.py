@@ -55,6 +55,7 @@ class BucketedAllReduce:
         self.pending = [0] * len(spans)
         self.handles: List = []
         self.comm_stream = torch.cuda.Stream() if flat.grad.is_cuda else None
+        self.index_of = {id(p): i for i, p in enumerate(flat.params)}
         for i, p in enumerate(flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
         self.launch_order: List[int] = []
@@ -73,6 +74,10 @@ class BucketedAllReduce:
             if self.pending[b] == 0:
                 self._launch(b)
         return hook
+
+    def notify(self, p):
+        """Called by the direct gradient sink (kdrt.gradsink) when p's gradient has been written."""
+        self._make_hook(self.index_of[id(p)])(p)
 
     def _launch(self, b):
         self.launch_order.append(b)

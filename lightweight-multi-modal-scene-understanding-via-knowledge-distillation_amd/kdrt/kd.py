@@ -10,6 +10,7 @@ from typing import Optional
 
 import torch
 
+from . import gradsink
 from .ddp import BucketedAllReduce
 from .losses import kd_objective
 from .optim import FusedAdamW
@@ -22,6 +23,7 @@ class KDStep:
         self.student, self.teacher, self.opt = student, teacher, optimizer
         self.cw, self.T, self.alpha, self.beta, self.ignore_index = class_weights, T, alpha, beta, ignore_index
         self.reducer = reducer
+        self.sink = gradsink.install(optimizer.flat, reducer)      # backward kernels write into the flat grad buffer
         self.teacher.eval()
         for p in self.teacher.parameters():
             p.requires_grad_(False)
@@ -29,6 +31,8 @@ class KDStep:
     def __call__(self, images, points, labels):
         with torch.no_grad():
             zt, mt = self.teacher(images, points, return_intermediates=True)
+        gradsink.active = self.sink
+        self.sink.begin_step()
         self.opt.zero_grad()
         zs, ms = self.student(images, points, return_intermediates=True)
         total, parts = kd_objective(zs, ms, zt, mt, labels, self.cw, self.T, self.alpha, self.beta, self.ignore_index)

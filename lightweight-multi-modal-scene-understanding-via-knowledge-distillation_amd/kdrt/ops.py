@@ -182,10 +182,15 @@ def bn_bwd_reduce(D, op: Operand):
     return partial, rows
 
 
-def bn_bwd_finalize(partial, rows, C, count, gamma, bnc: BNC, training: bool, want_dbias=False, pstride=None):
-    """-> (dgamma, dbeta, abg[3,C], dbias|None)"""
+def bn_bwd_finalize(partial, rows, C, count, gamma, bnc: BNC, training: bool, want_dbias=False, pstride=None,
+                    dgamma=None, dbeta=None, dbias=None):
+    """-> (dgamma, dbeta, abg[3,C], dbias|None); dgamma/dbeta/dbias may be caller-provided destinations."""
     dev = partial.device
     out = torch.empty(6, C, device=dev, dtype=torch.float32)
+    dgamma = out[0] if dgamma is None else dgamma
+    dbeta = out[1] if dbeta is None else dbeta
+    if want_dbias and dbias is None:
+        dbias = out[5]
     lib.call("kd_bn_bwd_finalize", P(partial), rows, C, pstride or C, count, P(gamma), P(bnc.mean), P(bnc.invstd), int(training),
-             P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(out[4]), P(out[5]) if want_dbias else None, stream())
-    return out[0], out[1], out[2:5], (out[5] if want_dbias else None)
+             P(dgamma), P(dbeta), P(out[2]), P(out[3]), P(out[4]), P(dbias) if want_dbias else None, stream())
+    return dgamma, dbeta, out[2:5], (dbias if want_dbias else None)

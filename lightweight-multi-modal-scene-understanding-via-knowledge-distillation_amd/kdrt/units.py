@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence
 
 import torch
 
-from . import ops
+from . import gradsink, ops
 from .lib import KDError, lib
 from .ops import ACT_NONE, ACT_RELU, ACT_RELU6, BNC, Operand, P, ld, stream
 
@@ -39,12 +39,24 @@ class _Rec:
 
 
 def _coeffs(spec: UnitSpec, partial, rows, C, count, training, bnc=None, device=None):
-    bnc = bnc if bnc is not None else BNC(C, device)
     if training:
+        bnc = bnc if bnc is not None else BNC(C, device)
         ops.bn_finalize_train(partial, rows, C, count, spec.bn, bnc)
-    else:
-        ops.bn_eval_coeffs(spec.bn, bnc)
-    return bnc
+        return bnc
+    # eval mode: the coefficients only depend on the BN's own tensors -- cache them until one changes
+    # (a frozen teacher otherwise recomputes 31 identical coefficient vectors every step)
+    bn = spec.bn
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr(), bn.running_mean.data_ptr())
+    if bnc is None:
+        hit = getattr(bn, "_kd_eval_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+    fresh = bnc if bnc is not None else BNC(C, device)
+    ops.bn_eval_coeffs(bn, fresh)
+    if bnc is None:
+        bn._kd_eval_cache = (key, fresh)
+    return fresh
 
 
 def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] = None, bnc: Optional[BNC] = None):
@@ -142,8 +154,14 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
         t, partial, rows = g[1], g[2], g[3]
         pstride = g[4] if len(g) > 4 else None
         msc, msh, mact = None, None, ACT_NONE
+    beta_p = spec.bn.bias
+    g_buf, g_dir = gradsink.out_for(rec.gamma)
+    b_buf, b_dir = gradsink.out_for(beta_p)
+    want_dbias = spec.has_bias and spec.kind != "l0"
+    cb_buf, cb_dir = gradsink.out_for(rec.b) if want_dbias else (None, False)
     dgamma, dbeta, abg, dbias = ops.bn_bwd_finalize(partial, rows, C, M, rec.gamma, bnc, rec.training,
-                                                    want_dbias=spec.has_bias and spec.kind != "l0", pstride=pstride)
+                                                    want_dbias=want_dbias, pstride=pstride, dgamma=g_buf, dbeta=b_buf,
+                                                    dbias=cb_buf)
     al, be, ga = abg[0], abg[1], abg[2]
     dev = y.device
     kind = spec.kind
@@ -151,7 +169,7 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
     if kind == "pw":
         inp = rec.inp
         N, K = C, inp.C
-        dW = torch.empty_like(rec.w)
+        dW, w_dir = gradsink.out_for(rec.w)
         ops.pw_wgrad(t, inp.raw, dW, M=M, N=N, K=K, X=y, d_mode=2, d_act=mact, al=al, be=be, ga=ga, msc=msc, msh=msh,
                      a_mode=1 if inp.bnc is not None else 0, a_act=inp.act, asc=inp.sc, ash=inp.sh)
         if need_input_grad:
@@ -169,13 +187,13 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
                 ops.pw_gemm(t, Wt, dx, M=M, K=N, N=K, A2=y, pro=2, pro_act=mact, p=(al, be, ga, msc, msh),
                             addend=addend, epi=0)
                 g_in = dx
-        grads = [dW]
+        grads = [gradsink.finish(rec.w, dW, w_dir)]
     elif kind == "dw":
         inp = rec.inp
         B, H, W = inp.geom
         s = spec.stride
         npix_out = M
-        dW = torch.empty_like(rec.w)
+        dW, w_dir = gradsink.out_for(rec.w)
         nbytes = lib.kd_dwconv_bwd_ws_bytes(npix_out, C)
         ws = ops.workspace(nbytes, dev)
         gx = part_in = None
@@ -198,7 +216,7 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
                 if addend is not None:
                     ops.bn_act_apply(gx, None, None, ACT_NONE, gx, res=addend)
                 g_in = gx
-        grads = [dW]
+        grads = [gradsink.finish(rec.w, dW, w_dir)]
     elif kind == "stem":
         img = rec.image
         B, Cin, H, W = img.shape
@@ -207,7 +225,7 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
         lib.call("kd_stem_im2col", P(img), P(col), B, Cin, H, W, Kp, stream())
         dWp = torch.empty(C, Kp, device=dev, dtype=torch.float32)
         ops.pw_wgrad(t, col, dWp, M=M, N=C, K=Kp, X=y, d_mode=2, d_act=mact, al=al, be=be, ga=ga, msc=msc, msh=msh)
-        grads = [dWp[:, : Cin * 9].reshape(rec.w.shape)]
+        grads = [gradsink.deliver(rec.w, dWp[:, : Cin * 9])]
     elif kind == "l0":
         if g[0] != "G":
             raise KDError("LiDAR layer-0 backward expects a masked gradient")
@@ -216,10 +234,10 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
         ws = ops.workspace(nbytes, dev)
         dwb = torch.empty(C * 5, device=dev, dtype=torch.float32)
         lib.call("kd_lidar_l0_bwd", P(t), P(y), P(al), P(be), P(ga), P(pts), P(dwb), M, C, P(ws), nbytes, stream())
-        grads = [dwb[: C * 4].view(rec.w.shape), dwb[C * 4:]]
-    if spec.has_bias and kind != "l0":
-        grads.append(dbias)
-    grads += [dgamma, dbeta]
+        grads = [gradsink.deliver(rec.w, dwb[: C * 4]), gradsink.deliver(rec.b, dwb[C * 4:])]
+    if want_dbias:
+        grads.append(gradsink.finish(rec.b, dbias, cb_dir))
+    grads += [gradsink.finish(rec.gamma, dgamma, g_dir), gradsink.finish(beta_p, dbeta, b_dir)]
     return grads, g_in
 
 
@@ -422,7 +440,7 @@ class WeightedFuseFn(torch.autograd.Function):
         lib.call("kd_weighted_fuse_fwd", P(cat), P(comb.scale), P(comb.shift), P(hraw), P(w2), P(b2), P(out), P(wts), M, C,
                  stream())
         ctx.rec_c, ctx.rec_l, ctx.cat, ctx.comb, ctx.hraw, ctx.wts = rec_c, rec_l, cat, comb, hraw, wts
-        ctx.w1, ctx.w2, ctx.C, ctx.geom = w1, w2, C, geom
+        ctx.w1, ctx.w2, ctx.b1, ctx.b2, ctx.C, ctx.geom = w1, w2, b1, b2, C, geom
         return ops.nchw_from_matrix(out, geom)
 
     @staticmethod
@@ -438,10 +456,10 @@ class WeightedFuseFn(torch.autograd.Function):
         ws = ops.workspace(nbytes, dev)
         lib.call("kd_weighted_fuse_bwd", P(dm), P(cat), P(comb.scale), P(comb.shift), P(ctx.hraw), P(ctx.w2), P(ctx.wts),
                  P(dcat), P(gh), P(dpar), M, C, P(ws), nbytes, stream())
-        dw2 = dpar[: 2 * C].view(ctx.w2.shape)
-        db1 = dpar[2 * C: 3 * C]
-        db2 = dpar[3 * C: 3 * C + 2]
-        dw1 = torch.empty_like(ctx.w1)
+        dw2 = gradsink.deliver(ctx.w2, dpar[: 2 * C])
+        db1 = gradsink.deliver(ctx.b1, dpar[2 * C: 3 * C])
+        db2 = gradsink.deliver(ctx.b2, dpar[3 * C: 3 * C + 2])
+        dw1, w1_dir = gradsink.out_for(ctx.w1)
         ops.pw_wgrad(gh, cat, dw1, M=M, N=C, K=2 * C, d_mode=0, a_mode=1, a_act=ACT_RELU, asc=comb.scale, ash=comb.shift)
         w1t = ops.transpose(ctx.w1.view(C, 2 * C))
         rows = lib.kd_pwconv_stat_rows(M)
@@ -451,7 +469,7 @@ class WeightedFuseFn(torch.autograd.Function):
                     emean=comb.mean, einv=comb.invstd, epi_act=ACT_RELU, partial=partial)
         dcam, dlid, pg_c, pg_l = _proj_pair_backward(ctx, gcat, partial, rows, C, C, ctx.needs_input_grad[0],
                                                      ctx.needs_input_grad[1])
-        return (dcam, dlid, None, None, None, dw1, db1, dw2, db2, *pg_c, *pg_l)
+        return (dcam, dlid, None, None, None, gradsink.finish(ctx.w1, dw1, w1_dir), db1, dw2, db2, *pg_c, *pg_l)
 
 
 def run_weighted_fuse(cam, lid, u_cam, u_lid, att0, att2, training):
@@ -507,7 +525,7 @@ class SameHeadFn(torch.autograd.Function):
         logits = torch.empty(B, NC, H, W, device=xm.device, dtype=torch.float32)
         lib.call("kd_cls_conv_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(wc), P(bc), P(logits), cur.M, H * W, Cin,
                  NC, stream())
-        ctx.recs, ctx.last, ctx.wc = recs, cur, wc
+        ctx.recs, ctx.last, ctx.wc, ctx.bc = recs, cur, wc, bc
         return logits
 
     @staticmethod
@@ -528,7 +546,8 @@ class SameHeadFn(torch.autograd.Function):
                  P(wc), P(gx), P(partial), P(dwb), M, H * W, Cin, NC, P(ws), nbytes, stream())
         grads, g_in = chain_backward(ctx.recs, ("G", gx, partial, rows), need_input_grad=ctx.needs_input_grad[0])
         dx = ops.nchw_from_matrix(g_in, ctx.recs[0].inp.geom) if ctx.needs_input_grad[0] else None
-        return (dx, None, None, dwb[: NC * Cin].view(wc.shape), dwb[NC * Cin: NC * Cin + NC], *grads)
+        return (dx, None, None, gradsink.deliver(wc, dwb[: NC * Cin]), gradsink.deliver(ctx.bc, dwb[NC * Cin: NC * Cin + NC]),
+                *grads)
 
 
 def run_same_head(x, units, cls_conv, training):

@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 import torch.optim as optim
 
+from kdrt import gradsink
 from kdrt.ddp import BucketedAllReduce, broadcast_module
 from kdrt.kd import KDStep
 from kdrt.losses import confusion, seg_loss
@@ -79,6 +80,7 @@ class Trainer:
         self.criterion = lambda logits, seg: seg_loss(logits, seg, self.class_weights, self.ignore_index)[0]
         self.optimizer = FusedAdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
         self.scheduler = optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=num_epochs, eta_min=1e-5)
+        self.sink = gradsink.install(self.optimizer.flat)        # backward kernels write into the flat grad buffer
         self.save_dir = save_dir
         os.makedirs(save_dir, exist_ok=True)
         self.best_miou = 0.0
@@ -87,6 +89,8 @@ class Trainer:
 
     # one optimisation step; overridden by KDTrainer
     def _step(self, imgs, pts, seg):
+        gradsink.active = self.sink
+        self.sink.begin_step()
         self.optimizer.zero_grad()
         logits = self.model(imgs, pts)
         loss = self.criterion(logits, seg)
