@@ -45,7 +45,16 @@ __global__ __launch_bounds__(256, (PRO == 2 && WM == 4) ? 2 : 3) void pw_gemm_ke
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int nct = (g.N + BNt - 1) / BNt;
-  const int rowblk = blockIdx.x / nct, ct = blockIdx.x % nct;
+  // XCD-aware tile order (speed only, any placement is correct): workgroups are dealt round-robin
+  // over the 8 XCDs, so blocks b, b+8, b+16, ... share an L2.  Give those blocks the nct column
+  // tiles of ONE row block, so the A rows are fetched from HBM once and re-read from that XCD's L2
+  // (PMC before: FETCH_SIZE 1.3-1.76x the algorithmic bytes for N = 192..768).
+  int rowblk, ct;
+  {
+    const int nrb = (g.M + BMt - 1) / BMt, grp = 8 * nct, g0 = blockIdx.x / grp, r = blockIdx.x % grp;
+    if ((g0 + 1) * 8 <= nrb) { rowblk = g0 * 8 + (r & 7); ct = r >> 3; }
+    else { const int rem = nrb - g0 * 8; rowblk = g0 * 8 + r % rem; ct = r / rem; }
+  }
   const int64_t m0 = (int64_t)rowblk * BMt;
   const int n0 = ct * BNt;
   const int nk = (g.K + BK - 1) / BK;
