@@ -303,7 +303,7 @@ class FPNFn(torch.autograd.Function):
     largest stage -> running sum -> DWSeparableConv post block."""
 
     @staticmethod
-    def forward(ctx, n_stage, laterals, post_units, training, *tensors):
+    def forward(ctx, n_stage, laterals, post_units, training, target_size, *tensors):
         feats = tensors[:n_stage]
         lat_ops, lat_recs, in_geoms = [], [], []
         for f, u in zip(feats, laterals):
@@ -311,7 +311,7 @@ class FPNFn(torch.autograd.Function):
             op, rec = unit_forward(u, Operand(xm, geom), training)
             lat_ops.append(op); lat_recs.append(rec); in_geoms.append(geom)
         B = in_geoms[0][0]
-        Ho, Wo = max(((g[1], g[2]) for g in in_geoms), key=lambda hw: hw[0] * hw[1])
+        Ho, Wo = target_size if target_size is not None else max(((g[1], g[2]) for g in in_geoms), key=lambda hw: hw[0] * hw[1])
         Ct = lat_ops[0].C
         dev = lat_ops[0].raw.device
         fused = torch.empty(B * Ho * Wo, Ct, device=dev, dtype=torch.float32)
@@ -342,16 +342,47 @@ class FPNFn(torch.autograd.Function):
             partial = torch.empty(rows * 2 * C, device=dm.device, dtype=torch.float32)
             lib.call("kd_bilinear_bwd", P(dfused), P(op.raw), P(op.sc), P(op.sh), op.act, P(op.bnc.mean),
                      P(op.bnc.invstd), P(gin), P(partial), B, Hi, Wi, Ho, Wo, C, stream())
-            need = ctx.needs_input_grad[4 + i]
+            need = ctx.needs_input_grad[5 + i]
             pg, gx = unit_backward(rec, ("G", gin, partial, rows), need_input_grad=need)
             lat_grads += pg
             feat_grads.append(ops.nchw_from_matrix(gx, rec.inp.geom) if need else None)
-        return (None, None, None, None, *feat_grads, *lat_grads, *post_grads)
+        return (None, None, None, None, None, *feat_grads, *lat_grads, *post_grads)
 
 
-def run_fpn(feats: Sequence[torch.Tensor], laterals: Sequence[UnitSpec], post_units: Sequence[UnitSpec], training):
-    return FPNFn.apply(len(feats), list(laterals), list(post_units), training, *feats, *_params_of(laterals),
+def run_fpn(feats: Sequence[torch.Tensor], laterals: Sequence[UnitSpec], post_units: Sequence[UnitSpec], training,
+            target_size=None):
+    return FPNFn.apply(len(feats), list(laterals), list(post_units), training,
+                       tuple(target_size) if target_size is not None else None, *feats, *_params_of(laterals),
                        *_params_of(post_units))
+
+
+# =================================================================================================
+class ResizeFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode="bilinear", align_corners=False) on the HIP path -- the LiDAR-to-camera
+    grid resize of CompleteSegmentationModel.forward (fusion_module.py:239-240) and of the fusion
+    blocks' own forwards (:87-88, :102-103, :123-124)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        xm, (B, Hi, Wi) = ops.nhwc_view(x)
+        Ho, Wo = size
+        C = xm.shape[1]
+        out = torch.empty(B * Ho * Wo, C, device=xm.device, dtype=torch.float32)
+        lib.call("kd_bilinear_accum_fwd", P(xm), None, None, ACT_NONE, P(out), 0, B, Hi, Wi, Ho, Wo, C, stream())
+        ctx.geom = (B, Hi, Wi, Ho, Wo, C)
+        return ops.nchw_from_matrix(out, (B, Ho, Wo))
+
+    @staticmethod
+    def backward(ctx, dout):
+        dm, _ = ops.nhwc_view(dout)
+        B, Hi, Wi, Ho, Wo, C = ctx.geom
+        gin = torch.empty(B * Hi * Wi, C, device=dm.device, dtype=torch.float32)
+        lib.call("kd_bilinear_bwd", P(dm), None, None, None, ACT_NONE, None, None, P(gin), None, B, Hi, Wi, Ho, Wo, C, stream())
+        return ops.nchw_from_matrix(gin, (B, Hi, Wi)), None
+
+
+def run_resize(x, size):
+    return ResizeFn.apply(x, (int(size[0]), int(size[1])))
 
 
 # =================================================================================================

@@ -4,7 +4,7 @@ Class names, constructor signatures, attribute names (`camera_proj` vs `cam_proj
 `attention`, `laterals`, `post`, `block`, `cls`, ...), registration order and state_dict keys follow
 the reference (fusion_module.py:8-286).  Forward passes run through kdrt's HIP Functions; the
 layer objects only hold parameters.  What is NOT built yet fails loudly (NotImplementedError):
-the `x4` ConvTranspose head's forward and camera/LiDAR grids of different sizes.
+the `x4` ConvTranspose head's forward.
 """
 from typing import Dict, List, Optional, Tuple
 
@@ -64,18 +64,17 @@ class CameraFPNLite(nn.Module):
         self.target_size = target_size
 
     def forward(self, feats: Dict[str, torch.Tensor]) -> torch.Tensor:
-        if self.target_size is not None:
-            raise NotImplementedError("CameraFPNLite(target_size=...) is not built on the HIP path yet")
         xs = [feats[s] for s in self.stages_to_use]
         lats = [self.laterals[s].unit() for s in self.stages_to_use]
-        return U.run_fpn(xs, lats, self.post.units(), self.training)
+        return U.run_fpn(xs, lats, self.post.units(), self.training, self.target_size)
 
 
-def _check_same_size(cam_feat, lidar_feat):
+def _match_size(cam_feat, lidar_feat):
+    """Bilinear (align_corners=False) resize of the LiDAR map to the camera map when they differ
+    (reference fusion_module.py:239-240 and the fusion blocks' own forwards)."""
     if cam_feat.shape[-2:] != lidar_feat.shape[-2:]:
-        raise NotImplementedError(
-            f"camera features {tuple(cam_feat.shape[-2:])} and LiDAR grid {tuple(lidar_feat.shape[-2:])} differ; "
-            "the bilinear LiDAR resize (fusion_module.py:239-240) is not built on the HIP path yet")
+        lidar_feat = U.run_resize(lidar_feat, cam_feat.shape[-2:])
+    return lidar_feat
 
 
 class ConcatenationFusion(nn.Module):
@@ -90,7 +89,7 @@ class ConcatenationFusion(nn.Module):
             nn.ReLU())
 
     def run(self, cam_feat, lidar_feat):
-        _check_same_size(cam_feat, lidar_feat)
+        lidar_feat = _match_size(cam_feat, lidar_feat)
         return U.run_concat_fuse(cam_feat, lidar_feat, self.camera_proj.unit(), self.lidar_proj.unit(),
                                  [_dw_unit(self.fuse, 0), _pw_unit(self.fuse, 3)], self.training)
 
@@ -105,7 +104,7 @@ class MinimalFusion(nn.Module):
         self.lidar_proj = Conv1x1(lidar_ch, out_ch)
 
     def forward(self, cam_feat, lidar_feat):
-        _check_same_size(cam_feat, lidar_feat)
+        lidar_feat = _match_size(cam_feat, lidar_feat)
         return U.run_minimal_fuse(cam_feat, lidar_feat, self.cam_proj.unit(), self.lidar_proj.unit(), self.training)
 
 
@@ -118,7 +117,7 @@ class WeightedFusion(nn.Module):
                                        nn.Conv2d(out_ch, 2, kernel_size=1), nn.Softmax(dim=1))
 
     def forward(self, cam_feat, lidar_feat):
-        _check_same_size(cam_feat, lidar_feat)
+        lidar_feat = _match_size(cam_feat, lidar_feat)
         return U.run_weighted_fuse(cam_feat, lidar_feat, self.cam_proj.unit(), self.lidar_proj.unit(),
                                    self.attention[0], self.attention[2], self.training)
 
@@ -189,7 +188,7 @@ class CompleteSegmentationModel(nn.Module):
     def forward(self, images: torch.Tensor, points: torch.Tensor, return_intermediates: bool = False):
         cam_raw = self.camera_encoder(images)
         cam_feat = self.camera_fpn(cam_raw) if isinstance(cam_raw, dict) else cam_raw
-        lidar_feat = self.lidar_encoder(points)
+        lidar_feat = _match_size(cam_feat, self.lidar_encoder(points))       # fusion_module.py:238-240
         if isinstance(self.fusion, ConcatenationFusion):
             fused, pre_fusion = self.fusion.run(cam_feat, lidar_feat)
         else:

@@ -216,3 +216,33 @@ def test_losses_and_confusion():
     (3.0 * feature_mse(ag, b.cuda())).backward()
     (3.0 * torch.nn.functional.mse_loss(ac, b)).backward()
     assert max_err(ag.grad, ac.grad)[1] < TOL
+
+
+def test_lidar_resize_and_fpn_target_size():
+    """fusion_module.py:239-240 (LiDAR grid != camera grid) and CameraFPNLite(target_size=...)."""
+    import torch.nn.functional as F
+    from kdrt import units as U
+    from src.models.fusion_module import CameraFPNLite
+    g = torch.Generator().manual_seed(12)
+    for (hi, wi, ho, wo) in ((8, 8, 16, 16), (12, 10, 7, 9), (16, 16, 16, 16)):
+        x = torch.randn(2, 8, hi, wi, generator=g)
+        xg, xc = x.clone().cuda().requires_grad_(True), x.clone().requires_grad_(True)
+        y, yo = U.run_resize(xg, (ho, wo)), F.interpolate(xc, size=(ho, wo), mode="bilinear", align_corners=False)
+        assert max_err(y, yo)[1] < TOL
+        up = torch.randn(yo.shape, generator=g)
+        (y * up.cuda()).sum().backward(); (yo * up).sum().backward()
+        assert max_err(xg.grad, xc.grad)[1] < 5 * TOL
+    stages = ["stage3", "stage4"]
+    fpn = CameraFPNLite({"stage3": 64, "stage4": 128}, 128, stages, target_size=(10, 10))
+    st = _rand_state(fpn, 23)
+    fpn = fpn.cuda().train()
+    feats = {"stage3": torch.randn(2, 64, 12, 12, generator=g), "stage4": torch.randn(2, 128, 6, 6, generator=g)}
+    y = fpn({k: v.cuda() for k, v in feats.items()})
+    so = O.clone_state(st)
+    acc = None
+    for s_ in stages:
+        t = O.conv1x1_block(feats[s_], {("f." + k): v for k, v in so.items()}, f"f.laterals.{s_}", True)
+        t = F.interpolate(t, size=(10, 10), mode="bilinear", align_corners=False)
+        acc = t if acc is None else acc + t
+    yo = O.dwsep_block(acc, {("f." + k): v for k, v in so.items()}, "f.post", True)
+    assert y.shape == (2, 128, 10, 10) and max_err(y, yo)[1] < TOL
