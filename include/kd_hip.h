@@ -46,14 +46,15 @@ const char* kd_last_error_string(void);
  *          p0/p1/p2 = al/be/ga from kd_bn_bwd_finalize, p3/p4 = sc/sh of the mask or NULL)
  *   epi 0: store     epi 1: store + partial (sum, sum^2)      [forward, feeds kd_bn_finalize_train]
  *   epi 2: C *= act'(X*esc+esh); partial (sum C, sum C*xhat)  [dgrad, feeds kd_bn_bwd_finalize]
- * The dgrad call passes W = transposed weight [K_out=Cin][N_red=Cout] (kd_transpose). */
+ * The dgrad call passes W = transposed weight [K_out=Cin][N_red=Cout] (kd_transpose).
+ * m_dev (optional device int): data-dependent row count <= M read by the kernel itself (no host sync). */
 int64_t kd_pwconv_stat_rows(int64_t M);
 int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, int pro, int pro_act,
                    const float* p0, const float* p1, const float* p2, const float* p3, const float* p4,
                    const float* W, const float* bias, float* C, int64_t ldc, const float* addend,
                    int64_t ldadd, int epi, const float* X, int64_t ldx, const float* esc, const float* esh,
                    const float* emean, const float* einv, int epi_act, float* partial, int64_t M, int K, int N,
-                   void* stream);
+                   const int* m_dev, void* stream);
 /* weight gradient dW[N,K] = Deff[M,N]^T . Aeff[M,K] (split-M partial tiles in `ws`, fixed-order sum).
  * d_mode 0: Deff = D; d_mode 2: Deff = al*(D*mask(X*msc+msh)) + be*X + ga.  a_mode 0/1 like pro 0/1. */
 size_t kd_pwconv_wgrad_ws_bytes(int64_t M, int N, int K);
@@ -101,7 +102,7 @@ int kd_bn_bwd_finalize(float* partial, int rows, int C, int pstride, int64_t cou
 
 /* ---- LiDAR branch (lidar_encoder.py:25-35,42-99) ----------------------------------------------- */
 int kd_lidar_l0_fwd(const float* pts, const float* w, const float* b, float* y, float* partial, int64_t P, int C,
-                    void* stream);
+                    const int* p_dev, void* stream);
 size_t kd_lidar_l0_bwd_ws_bytes(int64_t P, int C);
 int kd_lidar_l0_bwd(const float* D, const float* Y, const float* al, const float* be, const float* ga,
                     const float* pts, float* dwb, int64_t P, int C, void* ws, size_t ws_bytes, void* stream);
@@ -116,6 +117,12 @@ int kd_lidar_scatter_max_bwd(const float* pts, const float* y, const float* sc, 
                              float y0, float y1, void* ws, size_t ws_bytes, void* stream);
 int kd_lidar_bev_index(const float* pts, int* cell, int64_t P, int H, int W, float x0, float x1, float y0,
                        float y1, void* stream);
+/* inference-only: compact the in-range points (arbitrary order) with their flat (batch, cell) row; `counter`
+ * (one device int, zeroed here) receives the count.  Then scatter-max over the pre-binned rows. */
+int kd_lidar_compact(const float* pts, float* out_pts, int* out_cell, int* counter, int B, int64_t N, int H, int W,
+                     float x0, float x1, float y0, float y1, void* stream);
+int kd_lidar_scatter_max_idx_fwd(const float* y, const float* sc, const float* sh, int act, const int* cell_idx,
+                                 float* grid, int64_t P, int C, int64_t ncells, const int* p_dev, void* stream);
 
 /* ---- FPN resize, weighted-fusion tail, classifier (fusion_module.py:58-63,115-120,170-173) ----- */
 int kd_bilinear_accum_fwd(const float* in, const float* sc, const float* sh, int act, float* out, int accumulate,

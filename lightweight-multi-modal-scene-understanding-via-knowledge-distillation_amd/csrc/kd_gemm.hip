@@ -30,6 +30,7 @@ struct GemmArgs {
   const float* esc; const float* esh; const float* emean; const float* einv; int epi_act;
   float* partial;                     // EPI1/2: [rowblocks][2][N]
   int M, K, N;
+  const int* m_dev;                   // optional: device-side row count (<= M); rows beyond it are skipped
 };
 
 // Tile shape: WM x WN waves of 64x64 each (WM*WN == 4): 128x128 for wide outputs, 256x64 when the
@@ -58,6 +59,11 @@ __global__ __launch_bounds__(256, (PRO == 2 && WM == 4) ? 2 : 3) void pw_gemm_ke
   const int64_t m0 = (int64_t)rowblk * BMt;
   const int n0 = ct * BNt;
   const int nk = (g.K + BK - 1) / BK;
+  if (g.m_dev) {                      // data-dependent M (compacted LiDAR points): no host round trip
+    const int mv = *g.m_dev;
+    g.M = mv < g.M ? mv : g.M;
+    if (m0 >= g.M) return;            // whole workgroup leaves before any barrier
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -432,7 +438,8 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
                    const float* p1, const float* p2, const float* p3, const float* p4, const float* W,
                    const float* bias, float* C, int64_t ldc, const float* addend, int64_t ldadd, int epi,
                    const float* X, int64_t ldx, const float* esc, const float* esh, const float* emean,
-                   const float* einv, int epi_act, float* partial, int64_t M, int K, int N, void* stream) {
+                   const float* einv, int epi_act, float* partial, int64_t M, int K, int N, const int* m_dev,
+                   void* stream) {
   KD_REQUIRE(A && W && C && M > 0 && K > 0 && N > 0, KD_ERR_ARG, "kd_pwconv_gemm: null pointer or empty shape");
   KD_REQUIRE(M < (int64_t)1 << 31, KD_ERR_SHAPE, "kd_pwconv_gemm: M=%lld too large", (long long)M);
   KD_REQUIRE(K % 4 == 0 && lda % 4 == 0, KD_ERR_SHAPE, "kd_pwconv_gemm: K=%d and lda=%lld must be multiples of 4", K, (long long)lda);
@@ -451,7 +458,7 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
   if (pro == 2 && !p3) { p3 = p0; p4 = p0; }          // mask disabled (act none): any valid vector will do
   KD_REQUIRE(K >= 4, KD_ERR_SHAPE, "kd_pwconv_gemm: K must be >= 4");
   GemmArgs g{A, lda, A2, lda2, p0, p1, p2, p3, p4, pro, pro_act, W, bias, C, ldc, addend, ldadd,
-             X, ldx, esc, esh, emean, einv, epi_act, partial, (int)M, K, N};
+             X, ldx, esc, esh, emean, einv, epi_act, partial, (int)M, K, N, m_dev};
   hipStream_t st = (hipStream_t)stream;
   const dim3 blk(256);
   // 256x64 tiles when the last column tile would be <= 64 wide (N = 32, 64, 192, ...)

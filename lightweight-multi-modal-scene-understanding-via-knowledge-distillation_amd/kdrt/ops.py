@@ -131,12 +131,12 @@ def _prof_end(e0, kind, flops, nbytes):
 
 
 def pw_gemm(A, W, C_out, *, M, K, N, A2=None, pro=0, pro_act=0, p=(None,) * 5, bias=None, addend=None, epi=0,
-            X=None, esc=None, esh=None, emean=None, einv=None, epi_act=0, partial=None):
+            X=None, esc=None, esh=None, emean=None, einv=None, epi_act=0, partial=None, m_dev=None):
     e0 = _prof_begin()
     lib.call("kd_pwconv_gemm", P(A), ld(A), P(A2), ld(A2) if A2 is not None else 0, pro, pro_act,
              P(p[0]), P(p[1]), P(p[2]), P(p[3]), P(p[4]), P(W), P(bias), P(C_out), ld(C_out),
              P(addend), ld(addend) if addend is not None else 0, epi, P(X), ld(X) if X is not None else 0,
-             P(esc), P(esh), P(emean), P(einv), epi_act, P(partial), M, K, N, stream())
+             P(esc), P(esh), P(emean), P(einv), epi_act, P(partial), M, K, N, P(m_dev), stream())
     # algorithmic bytes: every operand tensor of the launch read or written exactly once
     _prof_end(e0, "pw_gemm", 2.0 * M * N * K,
               4.0 * (M * K * (2 if pro == 2 else 1) + M * N * (1 + (epi == 2) + (addend is not None)) + N * K))

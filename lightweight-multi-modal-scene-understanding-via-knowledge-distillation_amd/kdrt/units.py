@@ -59,7 +59,8 @@ def _coeffs(spec: UnitSpec, partial, rows, C, count, training, bnc=None, device=
     return fresh
 
 
-def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] = None, bnc: Optional[BNC] = None):
+def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] = None, bnc: Optional[BNC] = None,
+                 m_dev: Optional[torch.Tensor] = None):
     """inp: Operand (or, for 'stem', the NCHW image tensor; for 'l0', the [P,4] points).
     Returns (output Operand, record for backward)."""
     rec = _Rec()
@@ -81,7 +82,7 @@ def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] 
             rows = lib.kd_pwconv_stat_rows(M)
             partial = torch.empty(rows * 2 * N, device=dev, dtype=torch.float32)
         ops.pw_gemm(inp.raw, w, y, M=M, K=K, N=N, pro=1 if inp.bnc is not None else 0, pro_act=inp.act,
-                    p=(inp.sc, inp.sh, None, None, None), bias=b, epi=1 if training else 0, partial=partial)
+                    p=(inp.sc, inp.sh, None, None, None), bias=b, epi=1 if training else 0, partial=partial, m_dev=m_dev)
         rec.out_geom = inp.geom
         rec.bnc = _coeffs(spec, partial, rows, N, M, training, bnc, dev)
     elif kind == "dw":
@@ -126,7 +127,7 @@ def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] 
         if training:
             rows = lib.kd_rowwise_stat_rows(Pn, C)
             partial = torch.empty(rows * 2 * C, device=dev, dtype=torch.float32)
-        lib.call("kd_lidar_l0_fwd", P(pts), P(w), P(b), P(y), P(partial), Pn, C, stream())
+        lib.call("kd_lidar_l0_fwd", P(pts), P(w), P(b), P(y), P(partial), Pn, C, P(m_dev), stream())
         rec.out_geom = (Pn, 1, 1)
         rec.bnc = _coeffs(spec, partial, rows, C, Pn, training, bnc, dev)
     else:
@@ -597,6 +598,26 @@ class LidarFn(torch.autograd.Function):
         if D != 4:
             raise KDError(f"LiDAR points must be [B, N, 4], got {tuple(points.shape)}")
         pts = points.contiguous().view(B * N, 4)
+        H, W = grid_hw
+        if not training and not torch.is_grad_enabled():
+            # Inference fast path (frozen teacher): out-of-range points influence nothing in eval mode
+            # (no batch statistics, never scattered), so compact them away before the point MLP.
+            dev = pts.device
+            cpts = torch.empty(B * N, 4, device=dev, dtype=torch.float32)
+            ccell = torch.empty(B * N, device=dev, dtype=torch.int32)
+            counter = torch.empty(1, device=dev, dtype=torch.int32)
+            lib.call("kd_lidar_compact", P(pts), P(cpts), P(ccell), P(counter), B, N, H, W, float(rng[0]), float(rng[1]),
+                     float(rng[2]), float(rng[3]), stream())
+            # the row count stays on the device: the kernels read it themselves (no host sync, the CPU keeps
+            # running a whole step ahead of the GPU)
+            C = units[-1].conv.weight.shape[0]
+            grid = torch.empty(B * H * W, C, device=dev, dtype=torch.float32)
+            cur = cpts
+            for u in units:
+                cur, _ = unit_forward(u, cur, False, m_dev=counter)
+            lib.call("kd_lidar_scatter_max_idx_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(ccell), P(grid), B * N, C,
+                     B * H * W, P(counter), stream())
+            return ops.nchw_from_matrix(grid, (B, H, W))
         cur = pts
         recs = []
         for u in units:

@@ -53,10 +53,10 @@ int main(int argc, char** argv) {
       for (int i = 0; i < reps; ++i) fn();
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / reps; };
-    float t1 = timeit([&] { RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, nullptr, C, s.N, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, partial, s.M, s.K, s.N, nullptr)); });
-    float t0 = timeit([&] { RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, nullptr, C, s.N, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, s.M, s.K, s.N, nullptr)); });
+    float t1 = timeit([&] { RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, nullptr, C, s.N, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, partial, s.M, s.K, s.N, nullptr, nullptr)); });
+    float t0 = timeit([&] { RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, nullptr, C, s.N, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, s.M, s.K, s.N, nullptr, nullptr)); });
     // dgrad: A = G [M,N], A2 = Y [M,N], W^T stored [K][N], out [M,K], X(epi) [M,K]
-    float t2 = timeit([&] { RC(kd_pwconv_gemm(A, s.N, A2, s.N, 2, 0, al, be, ga, nullptr, nullptr, W, nullptr, C, s.K, nullptr, 0, 2, X, s.K, sc, sh, mean, inv, 2, partial, s.M, s.N, s.K, nullptr)); });
+    float t2 = timeit([&] { RC(kd_pwconv_gemm(A, s.N, A2, s.N, 2, 0, al, be, ga, nullptr, nullptr, W, nullptr, C, s.K, nullptr, 0, 2, X, s.K, sc, sh, mean, inv, 2, partial, s.M, s.N, s.K, nullptr, nullptr)); });
     float t3 = timeit([&] { RC(kd_pwconv_wgrad(A, s.N, A2, s.N, 2, 0, al, be, ga, nullptr, nullptr, X, s.K, 1, 2, sc, sh, C, s.M, s.N, s.K, ws, wsb, nullptr)); });
     float tc = timeit([&] { hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, 0, (const float4*)A, (float4*)C, (size_t)s.M * s.K / 4, (size_t)s.M * s.N / 4); });
     printf("%-25s %8ld | %7.1fus %5.1fTF %4.2fTB/s | %7.1fus %5.1fTF | %7.1fus %5.1fTF %4.2fTB/s | %7.1fus %5.1fTF %4.2fTB/s | %7.1fus %4.2fTB/s\n", s.name, s.M,
