@@ -133,23 +133,31 @@ __global__ __launch_bounds__(256) void scatter_max_fwd_kernel(ScatArgs a) {
   const int tid = threadIdx.x;
   const int gidx = tid % a.groups, slot = tid / a.groups;
   if (slot >= a.slots) return;
-  const int c0 = gidx * 4;
-  const float4 sc = kd_ld4(a.sc + c0), sh = kd_ld4(a.sh + c0);
+  // Lane -> channel map for atomics: thread gidx owns channels gidx, gidx+G, gidx+2G, gidx+3G (G = C/4), so
+  // one atomic wave-instruction covers CONSECUTIVE words (whole 128-B segments) of a cell row instead of
+  // every 4th word of all its lines -- the shape the memory-side atomic units run at full rate.
+  const int G = a.groups;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sc[j] = a.sc[gidx + G * j]; sh[j] = a.sh[gidx + G * j]; }
   const int64_t P = (int64_t)a.B * a.N;
   const int HW = a.geo.H * a.geo.W;
   for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < P; p += (int64_t)gridDim.x * a.slots) {
     int cell;
     if (!bev_cell(kd_ld4(a.pts + p * 4), a.geo, cell)) continue;
-    const float4 v = kd_affine_act4(kd_ld4(a.y + p * a.C + c0), sc, sh, a.act);
-    unsigned* dst = reinterpret_cast<unsigned*>(a.grid + ((p / a.N) * HW + cell) * a.C + c0);
+    const float* yp = a.y + p * a.C + gidx;
+    unsigned* dst = reinterpret_cast<unsigned*>(a.grid + ((p / a.N) * HW + cell) * a.C + gidx);
+    float v[4];
+    unsigned cur[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = kd_act(kd_affine(yp[G * j], sc[j], sh[j]), a.act); cur[j] = dst[G * j]; }
     // The cell value only ever grows, so a (possibly stale) plain read that is already >= v proves
     // the atomic would be a no-op: ~12 points share a cell, most of them lose and skip the atomic.
-    const uint4 cur = *reinterpret_cast<const uint4*>(dst);
-    const unsigned ux = __float_as_uint(v.x), uy = __float_as_uint(v.y), uz = __float_as_uint(v.z), uw = __float_as_uint(v.w);
-    if (v.x > 0.f && ux > cur.x) atomicMax(dst + 0, ux);
-    if (v.y > 0.f && uy > cur.y) atomicMax(dst + 1, uy);
-    if (v.z > 0.f && uz > cur.z) atomicMax(dst + 2, uz);
-    if (v.w > 0.f && uw > cur.w) atomicMax(dst + 3, uw);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned u = __float_as_uint(v[j]);
+      if (v[j] > 0.f && u > cur[j]) atomicMax(dst + G * j, u);
+    }
   }
 }
 
@@ -349,18 +357,23 @@ __global__ __launch_bounds__(256) void scatter_max_idx_kernel(const float* __res
   const int tid = threadIdx.x;
   const int gidx = tid % groups, slot = tid / groups;
   if (slot >= slots) return;
-  const int c0 = gidx * 4;
-  const float4 s = kd_ld4(sc + c0), h = kd_ld4(sh + c0);
+  const int G = groups;                 // same consecutive-word lane map as scatter_max_fwd_kernel
+  float s[4], h[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s[j] = sc[gidx + G * j]; h[j] = sh[gidx + G * j]; }
   if (p_dev) { const int64_t pv = *p_dev; P = pv < P ? pv : P; }
   for (int64_t p = (int64_t)blockIdx.x * slots + slot; p < P; p += (int64_t)gridDim.x * slots) {
-    const float4 v = kd_affine_act4(kd_ld4(y + p * C + c0), s, h, act);
-    unsigned* dst = reinterpret_cast<unsigned*>(grid + (int64_t)cell_idx[p] * C + c0);
-    const uint4 cur = *reinterpret_cast<const uint4*>(dst);
-    const unsigned ux = __float_as_uint(v.x), uy = __float_as_uint(v.y), uz = __float_as_uint(v.z), uw = __float_as_uint(v.w);
-    if (v.x > 0.f && ux > cur.x) atomicMax(dst + 0, ux);
-    if (v.y > 0.f && uy > cur.y) atomicMax(dst + 1, uy);
-    if (v.z > 0.f && uz > cur.z) atomicMax(dst + 2, uz);
-    if (v.w > 0.f && uw > cur.w) atomicMax(dst + 3, uw);
+    const float* yp = y + p * C + gidx;
+    unsigned* dst = reinterpret_cast<unsigned*>(grid + (int64_t)cell_idx[p] * C + gidx);
+    float v[4];
+    unsigned cur[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = kd_act(kd_affine(yp[G * j], s[j], h[j]), act); cur[j] = dst[G * j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned u = __float_as_uint(v[j]);
+      if (v[j] > 0.f && u > cur[j]) atomicMax(dst + G * j, u);
+    }
   }
 }
 int kd_lidar_scatter_max_idx_fwd(const float* y, const float* sc, const float* sh, int act, const int* cell_idx,
