@@ -116,11 +116,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # KD_REHEARSE_ON_ONE_GPU=1: every rank uses cuda:0 and the gloo backend -- only to rehearse the N>1
+    # code path (broadcast, bucketed async all-reduce, MAX-reduced timing) on a 1-GPU box; never a result.
+    rehearse = os.environ.get("KD_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)        # "nccl" is RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)    # "nccl" is RCCL on ROCm
 
     from kdrt import ops
     from kdrt.ddp import BucketedAllReduce, broadcast_module
@@ -160,7 +168,8 @@ def main():
     out = {
         "metric": "PandaSet 2-class KD training frames/sec", "value": round(frames / elapsed, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a result)" if rehearse else ""),
         "config": {
             "workload": "KD step: concat-fusion teacher fwd (eval) -> weighted-fusion student fwd/bwd (train BN), "
                         "CE + T^2*KL(T=4) + feature-MSE, fused AdamW; random-init weights",
@@ -169,13 +178,17 @@ def main():
             "parallelism": f"dp{world}" + (" (bucketed RCCL all-reduce overlapped with backward)" if world > 1 else "")},
     }
 
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
         # Live per-kernel timing of the dominant kernel family (the fp32-MFMA pointwise-conv GEMMs):
-        # HIP events around every GEMM launch on the launch stream, over 2 extra steps.
-        ops.PROFILE = []
+        # HIP events around every GEMM launch on the launch stream, over 2 extra steps.  EVERY rank runs
+        # the extra steps (they contain the gradient all-reduce: a rank-0-only step would deadlock the
+        # other ranks' collectives); only rank 0 records events and reports.
+        if rank == 0:
+            ops.PROFILE = []
         for _ in range(2):
             step(images, pts, labels)
-        torch.cuda.synchronize()
+        barrier()
+    if rank == 0 and not args.no_roofline:
         recs, ops.PROFILE = ops.PROFILE, None
         agg = {}
         for kind, flops, nbytes, e0, e1 in recs:

@@ -54,7 +54,6 @@ class BucketedAllReduce:
         self.views = [flat.grad[flat.offsets[a]:flat.offsets[e]] for a, e in spans]
         self.pending = [0] * len(spans)
         self.handles: List = []
-        self.comm_stream = torch.cuda.Stream() if flat.grad.is_cuda else None
         self.index_of = {id(p): i for i, p in enumerate(flat.params)}
         for i, p in enumerate(flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -83,23 +82,20 @@ class BucketedAllReduce:
         self.launch_order.append(b)
         if self.world == 1:
             return
-        if self.comm_stream is not None:
-            self.comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.comm_stream):
-                h = dist.all_reduce(self.views[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        else:
-            h = dist.all_reduce(self.views[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        # Canonical async collective: ProcessGroupNCCL (RCCL) runs it on its own internal stream, ordered
+        # after everything already enqueued on the current (compute) stream -- i.e. after this bucket's
+        # gradient kernels -- and `work.wait()` later makes the compute stream wait for it.  The launch
+        # order is the (deterministic) order in which backward finishes the buckets, identical on all ranks.
+        h = dist.all_reduce(self.views[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.handles.append(h)
 
     def finish(self):
-        """Call after backward: launches any bucket whose hooks did not all fire (unused parameters),
-        waits for the reductions, and makes the compute stream wait for the comm stream."""
+        """Call after backward: launches any bucket whose hooks did not all fire (unused parameters)
+        and makes the compute stream wait for the reductions (no host synchronisation with RCCL)."""
         for b in range(len(self.spans)):
             if self.pending[b] > 0:
                 self._launch(b)
         for h in self.handles:
             h.wait()
-        if self.comm_stream is not None and self.world > 1:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.reset()
         return 1.0 / self.world           # the factor the optimiser applies to the summed gradients
