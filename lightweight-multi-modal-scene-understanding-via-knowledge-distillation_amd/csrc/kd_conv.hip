@@ -90,7 +90,7 @@ __global__ void stem_im2col_kernel(const float* __restrict__ x, float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// depthwise 3x3 forward.  Thread = (pixel slot, 4-channel group); grid-stride over output pixels.
+// depthwise 3x3: argument blocks (kernels: the sliding-window family further down).
 struct DwArgs {
   const float* x; const float* sc; const float* sh; int act;     // deferred input (sc == null: plain)
   const float* w;                                                 // [C][9]
@@ -98,63 +98,6 @@ struct DwArgs {
   int B, H, W, C, Ho, Wo, stride;
   int groups, slots;
 };
-
-__global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
-  __shared__ float red[2 * 256 * 4];
-  const int tid = threadIdx.x;
-  const int gidx = tid % a.groups, slot = tid / a.groups;
-  const bool active = slot < a.slots;
-  const int c0 = gidx * 4;
-  float wreg[4][9];
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4();
-  if (active) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < 9; ++t) wreg[j][t] = a.w[(c0 + j) * 9 + t];
-    if (a.sc) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
-  }
-  float4 s1 = kd_zero4(), s2 = kd_zero4();
-  const int64_t npix = (int64_t)a.B * a.Ho * a.Wo;
-  if (active) {
-    for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < npix; p += (int64_t)gridDim.x * a.slots) {
-      const int wo = (int)(p % a.Wo), ho = (int)((p / a.Wo) % a.Ho), b = (int)(p / ((int64_t)a.Wo * a.Ho));
-      float4 acc = kd_zero4();
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int hi = ho * a.stride - 1 + kh;
-        if (hi < 0 || hi >= a.H) continue;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int wi = wo * a.stride - 1 + kw;
-          if (wi < 0 || wi >= a.W) continue;
-          float4 v = kd_ld4(a.x + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0);
-          if (a.sc) v = kd_affine_act4(v, sc, sh, a.act);
-          const int t = kh * 3 + kw;
-          acc.x = fmaf(v.x, wreg[0][t], acc.x);
-          acc.y = fmaf(v.y, wreg[1][t], acc.y);
-          acc.z = fmaf(v.z, wreg[2][t], acc.z);
-          acc.w = fmaf(v.w, wreg[3][t], acc.w);
-        }
-      }
-      kd_st4(a.y + p * a.C + c0, acc);
-      s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
-      s2.x = fmaf(acc.x, acc.x, s2.x); s2.y = fmaf(acc.y, acc.y, s2.y);
-      s2.z = fmaf(acc.z, acc.z, s2.z); s2.w = fmaf(acc.w, acc.w, s2.w);
-    }
-  }
-  if (a.partial) {
-    kd_st4(red + tid * 4, s1);
-    kd_st4(red + 1024 + tid * 4, s2);
-    __syncthreads();
-    for (int i = tid; i < 2 * a.C; i += 256) {
-      const int st = i / a.C, c = i % a.C;
-      float s = 0.f;
-      for (int sl = 0; sl < a.slots; ++sl) s += red[st * 1024 + (sl * a.groups + c / 4) * 4 + (c & 3)];
-      a.partial[((int64_t)blockIdx.x * 2 + st) * a.C + c] = s;
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // depthwise backward.  dyeff = kd_bwd_operand(D, Y, al, be, ga [, mask]) is the gradient w.r.t. the
@@ -182,133 +125,6 @@ __device__ __forceinline__ float4 dw_dyeff(const DwBwdArgs& a, int64_t q, int c0
   r.z = kd_bwd_operand(d.z, y.z, al.z, be.z, ga.z, dsc.z, dsh.z, a.d_act);
   r.w = kd_bwd_operand(d.w, y.w, al.w, be.w, ga.w, dsc.w, dsh.w, a.d_act);
   return r;
-}
-
-// data gradient: gx[b,hi,wi,c] = mask(z_in) * sum_{kh,kw : (hi+1-kh) % s == 0} dyeff[b,(hi+1-kh)/s,(wi+1-kw)/s,c] * w[c,kh,kw]
-__global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdArgs a) {
-  __shared__ float red[2 * 256 * 4];
-  const int tid = threadIdx.x;
-  const int gidx = tid % a.groups, slot = tid / a.groups;
-  const bool active = slot < a.slots;
-  const int c0 = gidx * 4;
-  float wreg[4][9];
-  float4 al = kd_zero4(), be = kd_zero4(), ga = kd_zero4(), dsc = kd_zero4(), dsh = kd_zero4();
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4(), mean = kd_zero4(), inv = kd_zero4();
-  if (active) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < 9; ++t) wreg[j][t] = a.w[(c0 + j) * 9 + t];
-    if (a.al) { al = kd_ld4(a.al + c0); be = kd_ld4(a.be + c0); ga = kd_ld4(a.ga + c0); }
-    if (a.dsc) { dsc = kd_ld4(a.dsc + c0); dsh = kd_ld4(a.dsh + c0); }
-    if (a.sc) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
-    if (a.mean) { mean = kd_ld4(a.mean + c0); inv = kd_ld4(a.invstd + c0); }
-  }
-  float4 s1 = kd_zero4(), s2 = kd_zero4();
-  const int64_t npix = (int64_t)a.B * a.H * a.W;
-  if (active) {
-    for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < npix; p += (int64_t)gridDim.x * a.slots) {
-      const int wi = (int)(p % a.W), hi = (int)((p / a.W) % a.H), b = (int)(p / ((int64_t)a.W * a.H));
-      float4 acc = kd_zero4();
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int th = hi + 1 - kh;
-        if (th < 0 || th % a.stride) continue;
-        const int ho = th / a.stride;
-        if (ho >= a.Ho) continue;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int tw = wi + 1 - kw;
-          if (tw < 0 || tw % a.stride) continue;
-          const int wo = tw / a.stride;
-          if (wo >= a.Wo) continue;
-          const float4 d = dw_dyeff(a, ((int64_t)b * a.Ho + ho) * a.Wo + wo, c0, al, be, ga, dsc, dsh);
-          const int t = kh * 3 + kw;
-          acc.x = fmaf(d.x, wreg[0][t], acc.x);
-          acc.y = fmaf(d.y, wreg[1][t], acc.y);
-          acc.z = fmaf(d.z, wreg[2][t], acc.z);
-          acc.w = fmaf(d.w, wreg[3][t], acc.w);
-        }
-      }
-      if (a.sc) {                       // mask by the input's activation, collect BN-backward sums
-        const float4 xr = kd_ld4(a.x + p * a.C + c0);
-        acc.x *= kd_act_mask(kd_affine(xr.x, sc.x, sh.x), a.act);
-        acc.y *= kd_act_mask(kd_affine(xr.y, sc.y, sh.y), a.act);
-        acc.z *= kd_act_mask(kd_affine(xr.z, sc.z, sh.z), a.act);
-        acc.w *= kd_act_mask(kd_affine(xr.w, sc.w, sh.w), a.act);
-        s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
-        s2.x = fmaf(acc.x, (xr.x - mean.x) * inv.x, s2.x);
-        s2.y = fmaf(acc.y, (xr.y - mean.y) * inv.y, s2.y);
-        s2.z = fmaf(acc.z, (xr.z - mean.z) * inv.z, s2.z);
-        s2.w = fmaf(acc.w, (xr.w - mean.w) * inv.w, s2.w);
-      }
-      kd_st4(a.gx + p * a.C + c0, acc);
-    }
-  }
-  if (a.partial) {
-    kd_st4(red + tid * 4, s1);
-    kd_st4(red + 1024 + tid * 4, s2);
-    __syncthreads();
-    for (int i = tid; i < 2 * a.C; i += 256) {
-      const int st = i / a.C, c = i % a.C;
-      float s = 0.f;
-      for (int sl = 0; sl < a.slots; ++sl) s += red[st * 1024 + (sl * a.groups + c / 4) * 4 + (c & 3)];
-      a.partial[((int64_t)blockIdx.x * 2 + st) * a.C + c] = s;
-    }
-  }
-}
-
-// weight gradient: dw[c,kh,kw] = sum_{b,ho,wo} dyeff[b,ho,wo,c] * xact[b,ho*s-1+kh,wo*s-1+kw,c]
-__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(DwBwdArgs a) {
-  __shared__ float red[256 * 4];
-  const int tid = threadIdx.x;
-  const int gidx = tid % a.groups, slot = tid / a.groups;
-  const bool active = slot < a.slots;
-  const int c0 = gidx * 4;
-  float4 al = kd_zero4(), be = kd_zero4(), ga = kd_zero4(), dsc = kd_zero4(), dsh = kd_zero4();
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4();
-  if (active) {
-    if (a.al) { al = kd_ld4(a.al + c0); be = kd_ld4(a.be + c0); ga = kd_ld4(a.ga + c0); }
-    if (a.dsc) { dsc = kd_ld4(a.dsc + c0); dsh = kd_ld4(a.dsh + c0); }
-    if (a.sc) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
-  }
-  float4 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) acc[t] = kd_zero4();
-  const int64_t npix = (int64_t)a.B * a.Ho * a.Wo;
-  if (active) {
-    for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < npix; p += (int64_t)gridDim.x * a.slots) {
-      const int wo = (int)(p % a.Wo), ho = (int)((p / a.Wo) % a.Ho), b = (int)(p / ((int64_t)a.Wo * a.Ho));
-      const float4 d = dw_dyeff(a, p, c0, al, be, ga, dsc, dsh);
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int hi = ho * a.stride - 1 + kh;
-        if (hi < 0 || hi >= a.H) continue;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int wi = wo * a.stride - 1 + kw;
-          if (wi < 0 || wi >= a.W) continue;
-          float4 v = kd_ld4(a.x + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0);
-          if (a.sc) v = kd_affine_act4(v, sc, sh, a.act);
-          const int t = kh * 3 + kw;
-          acc[t].x = fmaf(d.x, v.x, acc[t].x);
-          acc[t].y = fmaf(d.y, v.y, acc[t].y);
-          acc[t].z = fmaf(d.z, v.z, acc[t].z);
-          acc[t].w = fmaf(d.w, v.w, acc[t].w);
-        }
-      }
-    }
-  }
-  for (int t = 0; t < 9; ++t) {         // reduce the row slots of this block, one tap at a time
-    __syncthreads();
-    kd_st4(red + tid * 4, acc[t]);
-    __syncthreads();
-    for (int c = tid; c < a.C; c += 256) {
-      float s = 0.f;
-      for (int sl = 0; sl < a.slots; ++sl) s += red[(sl * a.groups + c / 4) * 4 + (c & 3)];
-      a.wslab[(int64_t)blockIdx.x * a.C * 9 + c * 9 + t] = s;
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------

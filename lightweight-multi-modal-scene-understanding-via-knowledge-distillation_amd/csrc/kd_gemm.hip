@@ -9,12 +9,12 @@
 // affine of (G, X)), so no normalised / activated tensor is ever written to HBM.
 //
 // MFMA: v_mfma_f32_32x32x2_f32 -- fp32 in, fp32 accumulate, bit-exact fmaf chain, 157 TFLOP/s
-// dense peak on MI355X.  Tiles: 128x128 per 256-thread workgroup, 4 waves x (2x2) 32x32 tiles.
+// dense peak on MI355X.  Tiles: 128x128 (or 256x64) per 256-thread workgroup, 4 waves x (2x2) 32x32 MFMA tiles.
 #include "kd_common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDSLD = 36;  // 36-float rows: ds_read_b128 conflict-free
+constexpr int BM = 128, BK = 32, LDSLD = 36;   // BM: slab-row granularity; 36-float LDS rows: ds_read_b128 conflict-free
 
 struct GemmArgs {
   const float* A; int64_t lda;        // PRO0/1: raw activations; PRO2: D (gradient)
