@@ -156,6 +156,10 @@ int kd_argmax_confusion(const float* logits, const int64_t* target, int ignore_i
                         int64_t* pred, int B, int NC, int HW, void* stream);
 int kd_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float ginv, void* stream);
+/* hipGraph-replay-safe form: state = device float[4] {lr, step, 1-beta1^step, sqrt(1-beta2^step)}; the call
+ * advances state[1] on the device and refreshes the bias corrections before the update. */
+int kd_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, float beta1,
+                      float beta2, float eps, float weight_decay, float ginv, void* stream);
 
 #ifdef __cplusplus
 }

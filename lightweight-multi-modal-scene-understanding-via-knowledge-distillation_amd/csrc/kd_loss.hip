@@ -259,4 +259,41 @@ int kd_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float
   return kd_check_launch("kd_adamw_step");
 }
 
+// Graph-replay-safe AdamW: everything that changes from step to step lives in a device array
+//   state[0] = lr   state[1] = step count (as float)   state[2] = 1 - beta1^step   state[3] = sqrt(1 - beta2^step)
+// The tick kernel advances the step and refreshes the bias corrections; the update kernel reads them.
+// A captured hipGraph of the training step therefore stays correct on every replay (a host-side
+// `step` argument would be frozen at capture time).  lr is changed by writing state[0] between replays.
+__global__ void adamw_tick_kernel(float* state, float b1, float b2) {
+  const float t = state[1] + 1.f;
+  state[1] = t;
+  state[2] = (float)(1.0 - pow((double)b1, (double)t));
+  state[3] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* p, const float* g, float* m, float* v, int64_t n,
+                                                        const float* state, float b1, float b2, float eps, float wd,
+                                                        float ginv) {
+  const float lr = state[0], bc1 = state[2], bc2sqrt = state[3];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * ginv;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+int kd_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, float beta1, float beta2,
+                      float eps, float weight_decay, float ginv, void* stream) {
+  KD_REQUIRE(p && g && m && v && state && n > 0, KD_ERR_ARG, "kd_adamw_step_dev: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, st, state, beta1, beta2);
+  int64_t grid = (n + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)grid), dim3(256), 0, st, p, g, m, v, n, (const float*)state, beta1,
+                     beta2, eps, weight_decay, ginv);
+  return kd_check_launch("kd_adamw_step_dev");
+}
+
 }  // extern "C"

@@ -42,3 +42,59 @@ class KDStep:
         parts["total"] = total.detach()
         parts["logits"] = zs.detach()
         return parts
+
+
+class GraphedKDStep:
+    """The whole KD step captured ONCE into a hipGraph (through torch.cuda.CUDAGraph) and replayed:
+    ~600 kernel launches become one graph launch, so small per-GPU batches (the reference trains at
+    B=4) are no longer bound by the ~5.8 ms of host launch work per step.  Everything that varies
+    between steps lives on the device: the batch is copied into static input buffers, the AdamW
+    step counter / bias corrections / learning rate are device state (kd_adamw_step_dev), BatchNorm
+    running statistics are updated by the kernels themselves.
+
+    Restrictions: fixed batch shape; single GPU (the RCCL all-reduce is not captured here); call
+    `optimizer.sync_lr()` happens automatically before each replay."""
+
+    def __init__(self, step: KDStep, images, points, labels, warmup: int = 3):
+        if step.reducer is not None:
+            raise RuntimeError("GraphedKDStep: multi-GPU capture is not supported; use KDStep")
+        self.step = step
+        self.images, self.points, self.labels = images.clone(), points.clone(), labels.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up on a side stream (allocator, workspaces, caches)
+            for _ in range(warmup):
+                self.out = step(self.images, self.points, self.labels)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        step.opt.sync_lr()
+        with torch.cuda.graph(self.graph):
+            self.out = self._body()
+        self.replays = 0
+
+    def _body(self):
+        s = self.step
+        with torch.no_grad():
+            zt, mt = s.teacher(self.images, self.points, return_intermediates=True)
+        gradsink.active = s.sink
+        s.sink.begin_step()
+        s.opt.zero_grad()
+        zs, ms = s.student(self.images, self.points, return_intermediates=True)
+        total, parts = kd_objective(zs, ms, zt, mt, self.labels, s.cw, s.T, s.alpha, s.beta, s.ignore_index)
+        total.backward()
+        s.opt.enqueue_update()
+        parts["total"] = total.detach()
+        parts["logits"] = zs.detach()
+        return parts
+
+    def __call__(self, images=None, points=None, labels=None):
+        if images is not None:
+            self.images.copy_(images, non_blocking=True)
+            self.points.copy_(points, non_blocking=True)
+            self.labels.copy_(labels, non_blocking=True)
+        self.step.opt.sync_lr()
+        self.graph.replay()
+        self.step.opt.note_steps(1)
+        self.replays += 1
+        return self.out

@@ -51,6 +51,10 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
         self._step = 0
         self.grad_scale = 1.0            # set to 1/world_size by the DDP wrapper (sum all-reduce)
+        # step-to-step state lives on the device so a captured hipGraph of the step replays correctly:
+        # dev_state = [lr, step, 1-beta1^step, sqrt(1-beta2^step)]   (kd_adamw_step_dev)
+        self.dev_state = torch.zeros(4, device=self.flat.data.device, dtype=torch.float32)
+        self._dev_lr = None
         for p, o in zip(self.flat.params, self.flat.offsets):
             n = p.numel()
             self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.exp_avg[o:o + n].view(p.shape),
@@ -59,15 +63,32 @@ class FusedAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
 
+    def sync_lr(self):
+        """Push the current learning rate to the device state (call after a scheduler step; cheap no-op otherwise)."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._dev_lr:
+            self.dev_state[0:1].fill_(lr)
+            self._dev_lr = lr
+
+    def enqueue_update(self):
+        """The device part of a step (two kernel launches, graph-capturable)."""
+        g = self.param_groups[0]
+        lib.call("kd_adamw_step_dev", P(self.flat.data), P(self.flat.grad), P(self.exp_avg), P(self.exp_avg_sq),
+                 self.flat.numel, P(self.dev_state), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                 float(g["weight_decay"]), float(self.grad_scale), stream())
+
+    def note_steps(self, k: int = 1):
+        """Host-side bookkeeping for k device steps (state_dict compatibility with torch.optim.AdamW)."""
+        self._step += k
+        t = torch.tensor(float(self._step))
+        for st in self.state.values():
+            st["step"] = t
+
     @torch.no_grad()
     def step(self, closure=None):
-        g = self.param_groups[0]
-        self._step += 1
-        lib.call("kd_adamw_step", P(self.flat.data), P(self.flat.grad), P(self.exp_avg), P(self.exp_avg_sq), self.flat.numel,
-                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                 self._step, float(self.grad_scale), stream())
-        for st in self.state.values():
-            st["step"] = torch.tensor(float(self._step))
+        self.sync_lr()
+        self.enqueue_update()
+        self.note_steps(1)
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -82,3 +103,5 @@ class FusedAdamW(torch.optim.Optimizer):
             st["exp_avg_sq"] = self.exp_avg_sq[o:o + n].view(p.shape)
             steps.append(int(float(st["step"])))
         self._step = max(steps) if steps else 0
+        self.dev_state[1:2].fill_(float(self._step))
+        self._dev_lr = None

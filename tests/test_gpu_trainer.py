@@ -68,3 +68,36 @@ def test_kd_trainer_runs(tmp_path):
     assert l1 < l0
     assert all(torch.equal(a, b) for a, b in zip(before, teacher.parameters()))   # the teacher is frozen
     assert not teacher.training and student.training
+
+
+def test_graphed_kd_step_matches_eager():
+    """hipGraph capture of the whole KD step: N replays == N eager steps (parameters, Adam state, BN buffers)."""
+    import kd_oracle as O
+    from _gpu_util import build_product, load_random_state
+    from kdrt.kd import GraphedKDStep, KDStep
+    from kdrt.optim import FusedAdamW
+    B, HW, N, G = 2, 64, 512, 16
+    images, pts, labels = O.make_inputs(B, HW, N, G, 4, pad_tail=40)
+    images, pts, labels = images.cuda(), pts.cuda(), labels.cuda()
+    cw = torch.tensor([0.4, 3.5]).cuda()
+
+    def make():
+        teacher = build_product("concat", G); load_random_state(teacher, "concat", 11)
+        student = build_product("weighted", G); load_random_state(student, "weighted", 12); student.train()
+        opt = FusedAdamW(student.parameters(), lr=1e-3, weight_decay=1e-3)
+        return student, opt, KDStep(student, teacher, opt, cw)
+
+    s_e, opt_e, step_e = make()
+    for _ in range(6):                                   # 3 warm-up + 3: same count as the graphed run below
+        out_e = step_e(images, pts, labels)
+    s_g, opt_g, step_g = make()
+    graphed = GraphedKDStep(step_g, images, pts, labels, warmup=3)
+    for _ in range(3):
+        out_g = graphed(images, pts, labels)
+    torch.cuda.synchronize()
+    assert opt_g._step == 6 and abs(float(opt_g.dev_state[1]) - 6.0) < 1e-6      # 3 warm-up + 3 replays, host and device agree
+    assert abs(out_g["total"].item() - out_e["total"].item()) < 1e-5
+    for (n1, p1), (_, p2) in zip(s_e.named_parameters(), s_g.named_parameters()):
+        assert torch.allclose(p1, p2, atol=1e-6, rtol=1e-5), n1
+    for (n1, b1), (_, b2) in zip(s_e.named_buffers(), s_g.named_buffers()):
+        assert torch.allclose(b1.float(), b2.float(), atol=1e-6, rtol=1e-5), n1
