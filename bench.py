@@ -203,10 +203,21 @@ def main():
             "kernel": "pw_gemm_kernel<EPI> (1x1-conv fwd + dgrad, v_mfma_f32_32x32x2_f32)",
             "launches_per_step": g[3] // 2, "avg_launch_us": round(1e6 * g[2] / max(g[3], 1), 2),
             "algorithmic_gflop_per_launch": round(g[0] / max(g[3], 1) / 1e9, 3),
+            "algorithmic_mbyte_per_launch": round(g[1] / max(g[3], 1) / 1e6, 2),
             "algorithmic_GBps": round(g[1] / g[2] / 1e9, 1), "gemm_time_share_of_step": round(g[2] / 2 / (elapsed / args.steps), 3),
             "wgrad": {"achieved": round(w[0] / w[2] / 1e12, 2), "unit": "TFLOP/s", "launches_per_step": w[3] // 2,
                       "time_share_of_step": round(w[2] / 2 / (elapsed / args.steps), 3)},
         }
+        # HBM bytes per launch come from PMC counters, which need their own rocprofv3 passes: use the committed
+        # measurement of this exact workload (profiles/), null for any other configuration
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic_B128.json")))
+            wl = pmc["workload"]
+            if (wl["per_gpu_batch"], wl["points_per_frame"], wl["image"], wl["bev_grid"]) == (args.batch, args.points, args.image, args.grid):
+                out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_bench_pmc_traffic_B128.json)"
+        except (OSError, KeyError, ValueError):
+            pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(teacher, student, args.points, args.image, args.grid)
     if rank == 0:

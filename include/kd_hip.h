@@ -144,6 +144,25 @@ int kd_cls_conv_bwd(const float* dlog_nchw, const float* x, const float* sc, con
                     const float* mean, const float* invstd, const float* w, float* gx, float* partial, float* dwb,
                     int64_t M, int HW, int Cin, int NC, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- "x4" decoder head: LightweightSegmentationHead (fusion_module.py:142-159) ------------------
+ * ConvTranspose2d(k=4, s=2, p=1, bias=False) = kd_pwconv_gemm with W.view(Cin, Cout*16)^T (columns ordered
+ * co*16 + kh*4 + kw, the weight's own layout) followed by col2im; backward = im2col of the folded dy
+ * (al/be/ga of kd_bn_bwd_finalize, mask of the stage's own BN+ReLU) followed by the wgrad / dgrad GEMMs.
+ * cls3x3 = Conv2d(Cin<=32, NC<=4, 3, padding=1) over a deferred NHWC input, NCHW logits. */
+int64_t kd_deconv_stat_rows(int64_t npix_out, int Cout);
+int kd_deconv4x4s2_col2im_fwd(const float* col, float* out, float* partial, int B, int H, int W, int Cout,
+                             void* stream);
+int kd_deconv4x4s2_im2col_bwd(const float* D, const float* Y, const float* al, const float* be, const float* ga,
+                             const float* msc, const float* msh, int act, float* dcol, int B, int H, int W,
+                             int Cout, void* stream);
+int kd_cls3x3_fwd(const float* x, const float* sc, const float* sh, int act, const float* w, const float* b,
+                  float* logits_nchw, int B, int H, int W, int Cin, int NC, void* stream);
+int64_t kd_cls3x3_bwd_stat_rows(int64_t npix, int Cin);
+size_t kd_cls3x3_bwd_ws_bytes(int64_t npix, int Cin, int NC);
+int kd_cls3x3_bwd(const float* dlog_nchw, const float* x, const float* sc, const float* sh, int act,
+                  const float* mean, const float* invstd, const float* w, float* gx, float* partial, float* dwb,
+                  int B, int H, int W, int Cin, int NC, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- losses, metric, optimiser (trainer.py:18-37,55-56,86-90; KD terms are build-defined) ------ */
 size_t kd_seg_loss_ws_bytes(int64_t npix);
 int kd_seg_loss_fwd_bwd(const float* zs, const float* zt, const int64_t* target, const float* class_w,

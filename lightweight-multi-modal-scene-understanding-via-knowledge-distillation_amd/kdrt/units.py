@@ -20,7 +20,8 @@ from .ops import ACT_NONE, ACT_RELU, ACT_RELU6, BNC, Operand, P, ld, stream
 
 
 class UnitSpec:
-    """kind: 'pw' (1x1 conv / Conv1d k=1), 'dw' (depthwise 3x3), 'stem' (3x3 s2 dense), 'l0' (LiDAR 4->C)."""
+    """kind: 'pw' (1x1 conv / Conv1d k=1), 'dw' (depthwise 3x3), 'stem' (3x3 s2 dense), 'l0' (LiDAR 4->C),
+    'ct' (ConvTranspose2d k=4 s=2 p=1, bias-free: GEMM to [M_in, Cout*16] columns + col2im)."""
 
     def __init__(self, kind: str, conv, bn, act: int):
         self.kind, self.conv, self.bn, self.act = kind, conv, bn, act
@@ -130,6 +131,25 @@ def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] 
         lib.call("kd_lidar_l0_fwd", P(pts), P(w), P(b), P(y), P(partial), Pn, C, P(m_dev), stream())
         rec.out_geom = (Pn, 1, 1)
         rec.bnc = _coeffs(spec, partial, rows, C, Pn, training, bnc, dev)
+    elif kind == "ct":
+        B, H, W = inp.geom
+        Cin, Cout = w.shape[0], w.shape[1]
+        if tuple(w.shape[2:]) != (4, 4) or inp.C != Cin:
+            raise KDError(f"transposed conv expects a [{inp.C}, Cout, 4, 4] weight, got {tuple(w.shape)}")
+        dev = inp.raw.device
+        Wf = ops.transpose(w.view(Cin, Cout * 16))                     # [N = Cout*16, K = Cin]
+        col = torch.empty(inp.M, Cout * 16, device=dev, dtype=torch.float32)
+        ops.pw_gemm(inp.raw, Wf, col, M=inp.M, K=Cin, N=Cout * 16, pro=1 if inp.bnc is not None else 0, pro_act=inp.act,
+                    p=(inp.sc, inp.sh, None, None, None), epi=0)
+        Mo = B * 4 * H * W
+        y = torch.empty(Mo, Cout, device=dev, dtype=torch.float32)
+        partial, rows = None, 0
+        if training:
+            rows = lib.kd_deconv_stat_rows(Mo, Cout)
+            partial = torch.empty(rows * 2 * Cout, device=dev, dtype=torch.float32)
+        lib.call("kd_deconv4x4s2_col2im_fwd", P(col), P(y), P(partial), B, H, W, Cout, stream())
+        rec.out_geom = (B, 2 * H, 2 * W)
+        rec.bnc = _coeffs(spec, partial, rows, Cout, Mo, training, bnc, dev)
     else:
         raise KDError(f"unknown unit kind {kind}")
     rec.y = y
@@ -236,6 +256,30 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
         dwb = torch.empty(C * 5, device=dev, dtype=torch.float32)
         lib.call("kd_lidar_l0_bwd", P(t), P(y), P(al), P(be), P(ga), P(pts), P(dwb), M, C, P(ws), nbytes, stream())
         grads = [gradsink.deliver(rec.w, dwb[: C * 4]), gradsink.deliver(rec.b, dwb[C * 4:])]
+    elif kind == "ct":
+        inp = rec.inp
+        B, H, W = inp.geom
+        Cin, N16 = inp.C, C * 16
+        dcol = torch.empty(inp.M, N16, device=dev, dtype=torch.float32)
+        lib.call("kd_deconv4x4s2_im2col_bwd", P(t), P(y), P(al), P(be), P(ga), P(msc), P(msh), mact, P(dcol), B, H, W, C,
+                 stream())
+        dWt = torch.empty(N16, Cin, device=dev, dtype=torch.float32)     # (dW.view(Cin, Cout*16))^T
+        ops.pw_wgrad(dcol, inp.raw, dWt, M=inp.M, N=N16, K=Cin, a_mode=1 if inp.bnc is not None else 0, a_act=inp.act,
+                     asc=inp.sc, ash=inp.sh)
+        if need_input_grad:
+            Wd = rec.w.view(Cin, N16)                                     # dgrad operand [N = Cin, K = Cout*16] as stored
+            if inp.bnc is not None:
+                gin = torch.empty(inp.M, Cin, device=dev, dtype=torch.float32)
+                rows_in = lib.kd_pwconv_stat_rows(inp.M)
+                part_in = torch.empty(rows_in * 2 * Cin, device=dev, dtype=torch.float32)
+                ops.pw_gemm(dcol, Wd, gin, M=inp.M, K=N16, N=Cin, addend=addend, epi=2, X=inp.raw, esc=inp.sc, esh=inp.sh,
+                            emean=inp.bnc.mean, einv=inp.bnc.invstd, epi_act=inp.act, partial=part_in)
+                g_in = ("G", gin, part_in, rows_in)
+            else:
+                dx = torch.empty(inp.M, Cin, device=dev, dtype=torch.float32)
+                ops.pw_gemm(dcol, Wd, dx, M=inp.M, K=N16, N=Cin, addend=addend, epi=0)
+                g_in = dx
+        grads = [gradsink.deliver(rec.w, ops.transpose(dWt).view_as(rec.w))]
     if want_dbias:
         grads.append(gradsink.finish(rec.b, dbias, cb_dir))
     grads += [gradsink.finish(rec.gamma, dgamma, g_dir), gradsink.finish(beta_p, dbeta, b_dir)]
@@ -584,6 +628,53 @@ class SameHeadFn(torch.autograd.Function):
 
 def run_same_head(x, units, cls_conv, training):
     return SameHeadFn.apply(x, list(units), training, cls_conv.weight, cls_conv.bias, *_params_of(units))
+
+
+class X4HeadFn(torch.autograd.Function):
+    """LightweightSegmentationHead.forward (fusion_module.py:158-159): two ConvTranspose2d(4, 2, 1)+BN+ReLU
+    stages (each doubles H and W) then the 3x3 classifier (bias) writing NCHW logits."""
+
+    @staticmethod
+    def forward(ctx, x, units, training, wc, bc, *params):
+        xm, geom = ops.nhwc_view(x)
+        cur = Operand(xm, geom)
+        recs = []
+        for u in units:
+            cur, rec = unit_forward(u, cur, training)
+            recs.append(rec)
+        B, H, W = cur.geom
+        NC, Cin = wc.shape[0], wc.shape[1]
+        logits = torch.empty(B, NC, H, W, device=xm.device, dtype=torch.float32)
+        lib.call("kd_cls3x3_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(wc), P(bc), P(logits), B, H, W, Cin, NC,
+                 stream())
+        ctx.recs, ctx.last, ctx.wc, ctx.bc = recs, cur, wc, bc
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlog):
+        dlog = dlog.contiguous()
+        cur, wc = ctx.last, ctx.wc
+        B, H, W = cur.geom
+        NC, Cin = wc.shape[0], wc.shape[1]
+        M = cur.M
+        dev = dlog.device
+        gx = torch.empty(M, Cin, device=dev, dtype=torch.float32)
+        rows = lib.kd_cls3x3_bwd_stat_rows(M, Cin)
+        partial = torch.empty(rows * 2 * Cin, device=dev, dtype=torch.float32)
+        nw = NC * Cin * 9
+        dwb = torch.empty(nw + 4, device=dev, dtype=torch.float32)
+        nbytes = lib.kd_cls3x3_bwd_ws_bytes(M, Cin, NC)
+        ws = ops.workspace(nbytes, dev)
+        lib.call("kd_cls3x3_bwd", P(dlog), P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(cur.bnc.mean), P(cur.bnc.invstd),
+                 P(wc), P(gx), P(partial), P(dwb), B, H, W, Cin, NC, P(ws), nbytes, stream())
+        grads, g_in = chain_backward(ctx.recs, ("G", gx, partial, rows), need_input_grad=ctx.needs_input_grad[0])
+        dx = ops.nchw_from_matrix(g_in, ctx.recs[0].inp.geom) if ctx.needs_input_grad[0] else None
+        return (dx, None, None, gradsink.deliver(wc, dwb[:nw].view_as(wc)), gradsink.deliver(ctx.bc, dwb[nw: nw + NC]),
+                *grads)
+
+
+def run_x4_head(x, units, cls_conv, training):
+    return X4HeadFn.apply(x, list(units), training, cls_conv.weight, cls_conv.bias, *_params_of(units))
 
 
 # =================================================================================================

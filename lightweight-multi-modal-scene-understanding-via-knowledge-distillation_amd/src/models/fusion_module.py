@@ -3,8 +3,7 @@
 Class names, constructor signatures, attribute names (`camera_proj` vs `cam_proj`, `fuse`,
 `attention`, `laterals`, `post`, `block`, `cls`, ...), registration order and state_dict keys follow
 the reference (fusion_module.py:8-286).  Forward passes run through kdrt's HIP Functions; the
-layer objects only hold parameters.  What is NOT built yet fails loudly (NotImplementedError):
-the `x4` ConvTranspose head's forward.
+layer objects only hold parameters.
 """
 from typing import Dict, List, Optional, Tuple
 
@@ -133,9 +132,12 @@ class LightweightSegmentationHead(nn.Module):
                                  nn.BatchNorm2d(16), nn.ReLU())
         self.cls = nn.Conv2d(16, num_classes, kernel_size=3, padding=1)
 
+    def units(self):
+        return [U.UnitSpec("ct", self.up1[0], self.up1[1], ACT_RELU),
+                U.UnitSpec("ct", self.up2[0], self.up2[1], ACT_RELU)]
+
     def forward(self, x):
-        raise NotImplementedError("LightweightSegmentationHead (output_mode='x4') has no HIP kernels yet; "
-                                  "the training entry points use output_mode='same'")
+        return U.run_x4_head(x, self.units(), self.cls, self.training)
 
 
 class SameResolutionSegmentationHead(nn.Module):

@@ -7,7 +7,7 @@ from _util import state_template
 FUSIONS = {"concat": 256, "minimal": 128, "weighted": 128}
 
 
-def build_product(fusion, grid, num_classes=2, device="cuda"):
+def build_product(fusion, grid, num_classes=2, device="cuda", output_mode="same"):
     from src.models.camera_encoder import TwinLiteEncoder
     from src.models.fusion_module import CompleteSegmentationModel
     from src.models.lidar_encoder import LiDAREncoder
@@ -15,7 +15,7 @@ def build_product(fusion, grid, num_classes=2, device="cuda"):
     lid = LiDAREncoder(encoder_type="spatial", grid_size=(grid, grid), use_vectorized=True)
     m = CompleteSegmentationModel(cam, lid, num_classes=num_classes, fusion_type=fusion,
                                   fusion_out_channels=FUSIONS[fusion], camera_fpn_stages=["stage3", "stage4", "stage5"],
-                                  camera_fpn_channels=128, output_mode="same")
+                                  camera_fpn_channels=128, output_mode=output_mode)
     return m.to(device)
 
 

@@ -246,3 +246,37 @@ def test_lidar_resize_and_fpn_target_size():
         acc = t if acc is None else acc + t
     yo = O.dwsep_block(acc, {("f." + k): v for k, v in so.items()}, "f.post", True)
     assert y.shape == (2, 128, 10, 10) and max_err(y, yo)[1] < TOL
+
+
+@pytest.mark.parametrize("cin,nc,hw,training", [(256, 3, (16, 16), True), (128, 2, (8, 12), True), (128, 2, (7, 5), False)])
+def test_x4_head(cin, nc, hw, training):
+    """LightweightSegmentationHead (output_mode="x4", fusion_module.py:142-159): ConvTranspose2d as MFMA GEMM +
+    col2im, 3x3 classifier; forward, input gradient, every parameter gradient, BN running statistics."""
+    from src.models.fusion_module import LightweightSegmentationHead
+    torch.manual_seed(0)
+    m = LightweightSegmentationHead(cin, nc)
+    x = torch.randn(2, cin, *hw, generator=torch.Generator().manual_seed(5))
+    _compare(m, lambda xc, so: O.seg_head_x4(xc, {"h." + k: v for k, v in so.items()}, "h", training), x, 31,
+             training=training)
+
+
+def test_x4_model_matches_reference_fixture():
+    """Whole model with output_mode="x4" against the logits the reference produced (tests/golden/head_x4.npz;
+    the reference's own shape check is test_lidar_encoder.py:281-293)."""
+    from _util import golden
+    from _gpu_util import build_product
+    gd = golden("head_x4.npz")
+    B, HW, N, G = 2, 64, 512, 16
+    model = build_product("concat", G, num_classes=3, output_mode="x4")
+    st = O.randomize_state({k: v.detach().clone() for k, v in model.state_dict().items()}, 21)
+    for k, v in model.state_dict().items():
+        if k.endswith("grid_tensor"):
+            st[k] = v.clone()
+    model.load_state_dict(st)
+    model.cuda().eval()
+    images, pts, _ = O.make_inputs(B, HW, N, G, 6)
+    with torch.no_grad():
+        z = model(images.cuda(), pts.cuda())
+    assert z.shape == (2, 3, 64, 64)
+    ref = torch.from_numpy(gd["logits"])
+    assert (z.cpu() - ref).abs().max().item() < max(1e-4, 5e-6 * ref.abs().max().item())
