@@ -163,6 +163,22 @@ int kd_cls3x3_bwd(const float* dlog_nchw, const float* x, const float* sc, const
                   const float* mean, const float* invstd, const float* w, float* gx, float* partial, float* dwb,
                   int B, int H, int W, int Cin, int NC, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- per-frame input preparation (src/data_loading/pandaset_dataset.py:13-45,108-127) ------------------
+ * kd_bev_rasterize = remap_semantic (remap != 0: label = bit `id` of remap_bits, ids outside 0..63 -> 0) +
+ * rasterize_bev over B ragged frames (offsets: device int64 [B+1], points of frame b are [offsets[b], offsets[b+1])):
+ * mask[b,r,c] = label of the first point in input order of that cell with a non-zero label, else 0.  Range test is
+ * inclusive (x_min <= x <= x_max); cell = trunc((v - min) / span * (n-1)) in float32, span = max - min as the
+ * reference's float32 arithmetic sees it.  ws: kd_bev_rasterize_ws_bytes(B, H, W). */
+size_t kd_bev_rasterize_ws_bytes(int B, int H, int W);
+int kd_bev_rasterize(const float* x, const float* y, const int64_t* cls, const int64_t* offsets, int B, int64_t n_total,
+                     int remap, uint64_t remap_bits, int H, int W, float x_min, float x_span, float x_max, float y_min,
+                     float y_span, float y_max, void* ws, size_t ws_bytes, int64_t* mask, void* stream);
+int kd_semantic_remap(const int64_t* raw, int64_t n, uint64_t remap_bits, int64_t* out, void* stream);
+/* out[max_points,4] = stack(x,y,z,i) zero-padded, or (choice != NULL, n >= max_points) the rows choice[0..max_points) */
+int kd_points_prepare(const float* x, const float* y, const float* z, const float* intensity, const int64_t* choice,
+                      int64_t n, int64_t max_points, float* out, void* stream);
+int kd_image_u8hwc_to_f32chw(const uint8_t* in, float* out, int H, int W, void* stream);
+
 /* ---- losses, metric, optimiser (trainer.py:18-37,55-56,86-90; KD terms are build-defined) ------ */
 size_t kd_seg_loss_ws_bytes(int64_t npix);
 int kd_seg_loss_fwd_bwd(const float* zs, const float* zt, const int64_t* target, const float* class_w,

@@ -19,6 +19,7 @@ class KDError(RuntimeError):
 
 _CT = {
     "int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t,
+    "uint64_t": ctypes.c_uint64,
     "void": None,
 }
 
