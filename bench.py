@@ -23,8 +23,9 @@ sys.path.insert(0, PKG)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (same guide); a streaming copy reaches ~5.3-5.6 TB/s
 
 
 def build_models(grid):
@@ -174,7 +175,9 @@ def main():
             "workload": "KD step: concat-fusion teacher fwd (eval) -> weighted-fusion student fwd/bwd (train BN), "
                         "CE + T^2*KL(T=4) + feature-MSE, fused AdamW; random-init weights",
             "image": f"3x{args.image}x{args.image}", "points_per_frame": args.points, "bev_grid": f"{args.grid}x{args.grid}",
-            "num_classes": 2, "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+            "num_classes": 2, "gemm_arithmetic": ("fp32 operands as 3 bf16 pieces, 6 piece products on the bf16 matrix pipe, fp32 accumulate (fp32-grade)"
+                                                   if ops.get_gemm_arithmetic() == "split" else "exact fp32 MFMA products"),
+            "per_gpu_batch": args.batch, "global_batch": args.batch * world,
             "parallelism": f"dp{world}" + (" (bucketed RCCL all-reduce overlapped with backward)" if world > 1 else "")},
     }
 
@@ -196,17 +199,27 @@ def main():
             a[0] += flops; a[1] += nbytes; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += 1
         g = agg.get("pw_gemm", [0, 0, 1e-9, 0])
         w = agg.get("pw_wgrad", [0, 0, 1e-9, 0])
-        ach = g[0] / g[2] / 1e12
+        # The family is HBM-bound since its products moved to the bf16 matrix pipe (bf16x6 split arithmetic): the
+        # roofline is algorithmic bytes / launch time against the HBM peak.  The matrix-pipe view is kept beside it:
+        # fp32-equivalent FLOP/s (2MKN) and the bf16 FLOP/s actually executed (6 piece products per product).
+        arith = ops.get_gemm_arithmetic()
+        gbps = g[1] / g[2] / 1e9
+        tf = g[0] / g[2] / 1e12
         out["roofline"] = {
-            "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": "pw_gemm_kernel<EPI> (1x1-conv fwd + dgrad, v_mfma_f32_32x32x2_f32)",
+            "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+            "kernel": "pw_gemm_kernel<PRO,EPI> (1x1-conv fwd + dgrad; " +
+                      ("bf16x6 split products on v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if arith == "split"
+                       else "v_mfma_f32_32x32x2_f32)"),
             "launches_per_step": g[3] // 2, "avg_launch_us": round(1e6 * g[2] / max(g[3], 1), 2),
-            "algorithmic_gflop_per_launch": round(g[0] / max(g[3], 1) / 1e9, 3),
             "algorithmic_mbyte_per_launch": round(g[1] / max(g[3], 1) / 1e6, 2),
-            "algorithmic_GBps": round(g[1] / g[2] / 1e9, 1), "gemm_time_share_of_step": round(g[2] / 2 / (elapsed / args.steps), 3),
-            "wgrad": {"achieved": round(w[0] / w[2] / 1e12, 2), "unit": "TFLOP/s", "launches_per_step": w[3] // 2,
-                      "time_share_of_step": round(w[2] / 2 / (elapsed / args.steps), 3)},
+            "algorithmic_gflop_per_launch": round(g[0] / max(g[3], 1) / 1e9, 3),
+            "fp32_equivalent_tflops": round(tf, 2),
+            "matrix_pipe": ({"executed_bf16_tflops": round(6 * tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(6 * tf / MFMA_BF16_PEAK_TFLOPS, 4)}
+                            if arith == "split" else {"executed_fp32_tflops": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}),
+            "gemm_time_share_of_step": round(g[2] / 2 / (elapsed / args.steps), 3),
+            "wgrad": {"achieved": round(w[1] / w[2] / 1e9, 1), "unit": "GB/s", "fp32_tflops": round(w[0] / w[2] / 1e12, 2),
+                      "launches_per_step": w[3] // 2, "time_share_of_step": round(w[2] / 2 / (elapsed / args.steps), 3)},
         }
         # HBM bytes per launch come from PMC counters, which need their own rocprofv3 passes: use the committed
         # measurement of this exact workload (profiles/), null for any other configuration

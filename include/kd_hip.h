@@ -48,6 +48,10 @@ const char* kd_last_error_string(void);
  *   epi 2: C *= act'(X*esc+esh); partial (sum C, sum C*xhat)  [dgrad, feeds kd_bn_bwd_finalize]
  * The dgrad call passes W = transposed weight [K_out=Cin][N_red=Cout] (kd_transpose).
  * m_dev (optional device int): data-dependent row count <= M read by the kernel itself (no host sync). */
+/* Arithmetic of the GEMM family: 0 = exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = every fp32 operand split
+ * exactly into three bf16 pieces and the six leading piece products accumulated in fp32 on the bf16 matrix pipe
+ * (error <= 2^-23 |x||y| per product, i.e. fp32-grade).  Process-wide; returns the previous setting. */
+int kd_set_gemm_split(int on);
 int64_t kd_pwconv_stat_rows(int64_t M);
 int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, int pro, int pro_act,
                    const float* p0, const float* p1, const float* p2, const float* p3, const float* p4,

@@ -80,6 +80,16 @@ __device__ __forceinline__ float kd_bwd_operand(float d, float x, float al, floa
   return fmaf(al, g, fmaf(be, x, ga));
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is fence + s_barrier, and the fence makes hipcc
+// drain vmcnt to 0 first: every global load still in flight (register prefetch) and, worse, every global STORE
+// already issued is waited for at each barrier (~2-3 us per drained store burst in the GEMM epilogue).  Use this one
+// wherever the barrier only protects an LDS image; threads here never communicate through global memory.
+#ifdef KD_DBG_SYNCTHREADS
+__device__ __forceinline__ void kd_lds_barrier() { __syncthreads(); }
+#else
+__device__ __forceinline__ void kd_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+
 __device__ __forceinline__ float kd_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

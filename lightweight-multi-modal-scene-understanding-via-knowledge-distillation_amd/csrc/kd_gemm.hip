@@ -12,7 +12,27 @@
 // dense peak on MI355X.  Tiles: 128x128 (or 256x64) per 256-thread workgroup, 4 waves x (2x2) 32x32 MFMA tiles.
 #include "kd_common.h"
 
+#include <atomic>
+
 namespace {
+
+std::atomic<int> g_gemm_split{0};
+
+#ifdef KD_DBG_PHASES
+__device__ unsigned long long kd_dbg_counters[8];
+#define KD_STAMP(i) do { const long long t_ = clock64(); ph_acc[i] += t_ - ph_t; ph_t = t_; } while (0)
+#ifdef KD_DBG_EPI          // bins: 0 barrier | 1 MFMA tail + staging writes | 2 barrier | 3 row loop half 0 | 4 everything before the epilogue | 5 row loop half 1 + stats
+#define KD_PH(i) KD_STAMP(((i) == 5) ? 5 : 4)
+#define KD_PHE(i) KD_STAMP(i)
+#else
+#define KD_PH(i) KD_STAMP(i)
+#define KD_PHE(i) do {} while (0)
+#endif
+#else
+#define KD_PH(i) do {} while (0)
+#define KD_PHE(i) do {} while (0)
+#endif
+
 
 constexpr int BM = 128, BK = 32, LDSLD = 36;   // BM: slab-row granularity; 36-float LDS rows: ds_read_b128 conflict-free
 
@@ -36,13 +56,49 @@ struct GemmArgs {
 // Tile shape: WM x WN waves of 64x64 each (WM*WN == 4): 128x128 for wide outputs, 256x64 when the
 // last (or only) column tile would be at most 64 wide (N = 32, 64, 192, ...) so no MFMA work is
 // wasted on padding columns.
-template <int PRO, int EPI, int WM, int WN>
-__global__ __launch_bounds__(256, (PRO == 2 && WM == 4) ? 2 : 3) void pw_gemm_kernel(GemmArgs g) {
+//
+// SPLIT: the same GEMM on the bf16 matrix pipe.  Every fp32 operand element is cut into three bf16 pieces by
+// round-to-nearest (x = hi + mid + lo to 2^-26 relative) when its tile is written to LDS, and a product is the six
+// leading piece products
+//     hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid),      dropped: mid*lo + lo*mid + lo*lo <= 2^-25 |x||y|,
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (32 cycles for K = 16
+// against 8 x 64 cycles of v_mfma_f32_32x32x2_f32): 6 x 32 = 192 cycles per 32x32x16 block instead of 512, so the
+// near-ridge shapes of this network (AI 14..64 FLOP/B) become HBM-bound instead of matrix-pipe-bound.
+// LDS image: 3 planes per operand, rows of 32 bf16 padded to 40 (80 B: 16 consecutive rows x 16 B hit 64 banks once).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+constexpr int SPLD = 40;                                // bf16 per LDS row in the split image
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// two fp32 -> packed (hi | mid | lo) bf16 pairs, each piece rounded to nearest even by v_cvt_pk_bf16_f32:
+// |mid| <= 2^-9 |x|, |lo| <= 2^-17 |x|, x - (hi + mid + lo) <= 2^-26 |x|, residual signs unbiased.
+__device__ __forceinline__ void kd_split_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  f32x2 v = {x0, x1};
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  v[0] -= __uint_as_float(hi << 16);                 // exact (Sterbenz-like: hi shares the leading bits of x)
+  v[1] -= __uint_as_float(hi & 0xffff0000u);
+  mid = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  v[0] -= __uint_as_float(mid << 16);
+  v[1] -= __uint_as_float(mid & 0xffff0000u);
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+__device__ __forceinline__ void kd_split3(float4 v, uint2& hi, uint2& mid, uint2& lo) {
+  kd_split_pair(v.x, v.y, hi.x, mid.x, lo.x);
+  kd_split_pair(v.z, v.w, hi.y, mid.y, lo.y);
+}
+
+template <int PRO, int EPI, int WM, int WN, bool SPLIT>
+__global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) void pw_gemm_kernel(GemmArgs g) {
   constexpr int BMt = 64 * WM, BNt = 64 * WN;
   constexpr int AF = BMt / 32, BF = BNt / 32;          // float4 loads per thread per K-tile
-  __shared__ __attribute__((aligned(16))) float smem[(BMt + BNt) * LDSLD];
+  constexpr int SMEM_FLOATS = SPLIT ? (BMt + BNt) * 3 * SPLD / 2 : (BMt + BNt) * LDSLD;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   float* As = smem;
   float* Bs = smem + BMt * LDSLD;
+  unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);          // split image: A planes then B planes
+  unsigned short* Bh = Ah + 3 * BMt * SPLD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int nct = (g.N + BNt - 1) / BNt;
@@ -64,6 +120,8 @@ __global__ __launch_bounds__(256, (PRO == 2 && WM == 4) ? 2 : 3) void pw_gemm_ke
     g.M = mv < g.M ? mv : g.M;
     if (m0 >= g.M) return;            // whole workgroup leaves before any barrier
   }
+  // (A persistent variant -- one workgroup per resident slot walking tiles, next tile's first loads issued before
+  // the epilogue -- was measured 6-12 % SLOWER on the LiDAR shapes and is not kept.)
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -77,15 +135,30 @@ __global__ __launch_bounds__(256, (PRO == 2 && WM == 4) ? 2 : 3) void pw_gemm_ke
   // zeroed by a select in `transform`, which runs only when the tile is about to be written to LDS.
   // That keeps all loads of a tile in ONE basic block, issued back to back, in flight under the
   // MFMAs of the previous tile.  Per-channel coefficients depend only on (k0, tid & 7).
-  float4 ra[AF], rb[BF], rx[PRO == 2 ? AF : 1], co[PRO == 2 ? 5 : 2];
+  // PF2: a second register stage for the operand tiles (split arithmetic, 128x128 tile, PRO 0/1): the matrix work
+  // of one K-tile (~0.6 us) is shorter than the HBM latency under load, so two K-tiles of loads are kept in flight.
+  constexpr bool PF2 = SPLIT && PRO != 2 && WM == 2;
+  // Per-channel coefficients travel WITH their tile (loaded just before it): a coefficient load issued later than
+  // a prefetch would sit behind it in the in-order vmcnt queue and drain the prefetch when first used.  Only the
+  // fp32 PRO2 kernel (170-register budget at 3 workgroups/CU) fetches its five vectors at the point of use.
+  constexpr int NCO = PRO == 2 ? 5 : 2;
+  constexpr bool CO_LATE = PRO == 2 && !SPLIT;
+  float4 ra0[AF], rb0[BF], ra1[PF2 ? AF : 1], rb1[PF2 ? BF : 1], rx[PRO == 2 ? AF : 1], co0[NCO], co1[PF2 ? NCO : 1];
   const int c4 = tid & 7;
-  auto issue_loads = [&](int kt) {
+  auto issue_loads = [&](int kt, float4 (&ra)[AF], float4 (&rb)[BF], float4 (&co)[NCO]) {
     int gk = kt * BK + c4 * 4;
     gk = gk < g.K ? gk : g.K - 4;
+    if (PRO == 1) { co[0] = kd_ld4(g.p0 + gk); co[1] = kd_ld4(g.p1 + gk); }
+    if (PRO == 2 && !CO_LATE) {
+      co[0] = kd_ld4(g.p0 + gk); co[1] = kd_ld4(g.p1 + gk); co[2] = kd_ld4(g.p2 + gk); co[3] = kd_ld4(g.p3 + gk); co[4] = kd_ld4(g.p4 + gk);
+    }
 #pragma unroll
     for (int i = 0; i < AF; ++i) {
       int64_t gm = m0 + (tid >> 3) + 32 * i;
       gm = gm < g.M ? gm : (int64_t)g.M - 1;
+#ifdef KD_DBG_NOLDG
+      gm = (tid >> 3) + 32 * i;
+#endif
       ra[i] = kd_ld4(g.A + gm * g.lda + gk);
       if (PRO == 2) rx[i] = kd_ld4(g.A2 + gm * g.lda2 + gk);
     }
@@ -95,11 +168,10 @@ __global__ __launch_bounds__(256, (PRO == 2 && WM == 4) ? 2 : 3) void pw_gemm_ke
       gn = gn < g.N ? gn : g.N - 1;
       rb[i] = kd_ld4(g.W + (int64_t)gn * g.K + gk);
     }
-    if (PRO == 1) { co[0] = kd_ld4(g.p0 + gk); co[1] = kd_ld4(g.p1 + gk); }
   };
-  auto transform = [&](int kt) {
+  auto transform = [&](int kt, float4 (&ra)[AF], float4 (&rb)[BF], float4 (&co)[NCO]) {
     const bool kok = kt * BK + c4 * 4 < g.K;
-    if (PRO == 2) {   // 5 coefficient vectors: cache-resident, fetched here so they do not occupy 20 VGPRs under the MFMAs
+    if (CO_LATE) {    // 5 coefficient vectors: cache-resident, fetched here so they do not occupy 20 VGPRs under the MFMAs
       int gk = kt * BK + c4 * 4;
       gk = gk < g.K ? gk : g.K - 4;
       co[0] = kd_ld4(g.p0 + gk); co[1] = kd_ld4(g.p1 + gk); co[2] = kd_ld4(g.p2 + gk); co[3] = kd_ld4(g.p3 + gk); co[4] = kd_ld4(g.p4 + gk);
@@ -127,16 +199,70 @@ __global__ __launch_bounds__(256, (PRO == 2 && WM == 4) ? 2 : 3) void pw_gemm_ke
     }
   };
 
-  issue_loads(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    transform(kt);
-    __syncthreads();
+#ifdef KD_DBG_PHASES
+  long long ph_t = clock64(), ph_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  auto k_tile = [&](int kt, float4 (&ra)[AF], float4 (&rb)[BF], float4 (&co)[NCO]) {
+    transform(kt, ra, rb, co);
+    KD_PH(0);                          // wait for the tile's loads + BN/act transform
+    kd_lds_barrier();
+    KD_PH(1);                          // barrier: previous MFMA phase of the slowest wave
+    if (SPLIT) {
 #pragma unroll
-    for (int i = 0; i < AF; ++i) kd_st4(As + ((tid >> 3) + 32 * i) * LDSLD + c4 * 4, ra[i]);
+      for (int i = 0; i < AF; ++i) {
+        uint2 hi, mid, lo;
+        kd_split3(ra[i], hi, mid, lo);
+        unsigned short* d = Ah + ((tid >> 3) + 32 * i) * SPLD + c4 * 4;
+        *reinterpret_cast<uint2*>(d) = hi;
+        *reinterpret_cast<uint2*>(d + BMt * SPLD) = mid;
+        *reinterpret_cast<uint2*>(d + 2 * BMt * SPLD) = lo;
+      }
 #pragma unroll
-    for (int i = 0; i < BF; ++i) kd_st4(Bs + ((tid >> 3) + 32 * i) * LDSLD + c4 * 4, rb[i]);
-    __syncthreads();
-    if (kt + 1 < nk) issue_loads(kt + 1);  // next tile's HBM loads fly under this tile's MFMAs
+      for (int i = 0; i < BF; ++i) {
+        uint2 hi, mid, lo;
+        kd_split3(rb[i], hi, mid, lo);
+        unsigned short* d = Bh + ((tid >> 3) + 32 * i) * SPLD + c4 * 4;
+        *reinterpret_cast<uint2*>(d) = hi;
+        *reinterpret_cast<uint2*>(d + BNt * SPLD) = mid;
+        *reinterpret_cast<uint2*>(d + 2 * BNt * SPLD) = lo;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AF; ++i) kd_st4(As + ((tid >> 3) + 32 * i) * LDSLD + c4 * 4, ra[i]);
+#pragma unroll
+      for (int i = 0; i < BF; ++i) kd_st4(Bs + ((tid >> 3) + 32 * i) * LDSLD + c4 * 4, rb[i]);
+    }
+    KD_PH(2);                          // split + LDS stores
+    kd_lds_barrier();
+    KD_PH(3);                          // barrier after the LDS image
+    if (kt + (PF2 ? 2 : 1) < nk) issue_loads(kt + (PF2 ? 2 : 1), ra, rb, co);  // the freed stage refills under this tile's MFMAs
+    if (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[2][3], b[2][3];
+        const int ko = ks * 16 + (lane >> 5) * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            a[i][p] = *reinterpret_cast<const bf16x8*>(Ah + (p * BMt + wr * 64 + i * 32 + (lane & 31)) * SPLD + ko);
+            b[i][p] = *reinterpret_cast<const bf16x8*>(Bh + (p * BNt + wc * 64 + i * 32 + (lane & 31)) * SPLD + ko);
+          }
+        // smallest terms first; the four accumulators separate two uses of the same one by 3 other MFMAs
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+#ifdef KD_DBG_NOMFMA
+        for (int t = 0; t < 1; ++t)
+#else
+        for (int t = 0; t < 6; ++t)
+#endif
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PA[t]], b[ni][PB[t]], acc[mi][ni], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       f32x4 a[2], b[2];
@@ -154,7 +280,18 @@ __global__ __launch_bounds__(256, (PRO == 2 && WM == 4) ? 2 : 3) void pw_gemm_ke
           for (int ni = 0; ni < 2; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
     }
+  };
+  issue_loads(0, ra0, rb0, co0);
+  if constexpr (PF2) {
+    if (nk > 1) issue_loads(1, ra1, rb1, co1);
+    for (int kt = 0; kt < nk; kt += 2) {
+      k_tile(kt, ra0, rb0, co0);
+      if (kt + 1 < nk) k_tile(kt + 1, ra1, rb1, co1);
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) k_tile(kt, ra0, rb0, co0);
   }
+  KD_PH(4);                            // MFMA phases (incl. issuing the prefetch)
 
   // ---- epilogue ---------------------------------------------------------------------------------
   // The accumulator tile goes through LDS in two halves (the mi = 0 / 1 row groups of every wave) so
@@ -162,62 +299,102 @@ __global__ __launch_bounds__(256, (PRO == 2 && WM == 4) ? 2 : 3) void pw_gemm_ke
   // instead of 4-byte column-strided accesses.
   constexpr int TLD = BNt + 4;
   constexpr int CPT = BNt / 4, RG = 256 / CPT;        // column groups, row groups; 8 iterations cover WM*32 rows
-  static_assert(WM * 32 * TLD <= (BMt + BNt) * LDSLD, "epilogue staging must fit the operand LDS");
+  static_assert(WM * 32 * TLD <= SMEM_FLOATS, "epilogue staging must fit the operand LDS");
   float* T = smem;
   const int c4e = tid % CPT, rg = tid / CPT;
   const int col = n0 + c4e * 4;
   const bool cok = col < g.N;
+  // Per-column vectors: branch-free loads (clamped column, select), then ONE wait here in straight-line code.
+  // A load whose first use sits inside a conditional block keeps its registers "pending" for hipcc's waitcnt
+  // pass on the other path, and every later use then gets s_waitcnt vmcnt(0) -- which on gfx9 also waits for all
+  // earlier STORES: the row loop below used to drain its own store after every row.
+  const int colc = cok ? col : g.N - 4;
   float4 bias4 = kd_zero4(), esc = kd_zero4(), esh = kd_zero4(), emean = kd_zero4(), einv = kd_zero4();
-  if (cok) {
-    if (g.bias) bias4 = kd_ld4(g.bias + col);
-    if (EPI == 2) { esc = kd_ld4(g.esc + col); esh = kd_ld4(g.esh + col); emean = kd_ld4(g.emean + col); einv = kd_ld4(g.einv + col); }
+  {
+    const float* bp = g.bias ? g.bias : g.W;                 // any valid address; the value is dropped by the select
+    const float4 bv = kd_ld4(bp + (g.bias ? colc : 0));
+    const bool hb = g.bias != nullptr;
+    bias4 = make_float4(hb ? bv.x : 0.f, hb ? bv.y : 0.f, hb ? bv.z : 0.f, hb ? bv.w : 0.f);
+    if (EPI == 2) { esc = kd_ld4(g.esc + colc); esh = kd_ld4(g.esh + colc); emean = kd_ld4(g.emean + colc); einv = kd_ld4(g.einv + colc); }
   }
   float4 s1 = kd_zero4(), s2 = kd_zero4();
+  constexpr int NI = (WM * 32) / RG;                   // rows per thread per half
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    __syncthreads();                                 // LDS free: K-loop reads / previous half done
+    KD_PHE(h == 0 ? 4 : 3);
+    kd_lds_barrier();                                 // LDS free: K-loop reads / previous half done
+    KD_PHE(0);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         T[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TLD + wc * 64 + ni * 32 + (lane & 31)] = acc[h][ni][r];
-    __syncthreads();
+    KD_PHE(1);
+    kd_lds_barrier();
+    KD_PHE(2);
+    // All global LOADS of this half are issued before its first store (clamped addresses, no branches), so no
+    // wait on a load ever has an older store in front of it in the in-order vmcnt queue.
+    float4 xr[EPI == 2 ? NI : 1];
+    if (EPI == 2) {
 #pragma unroll
-    for (int i = 0; i < (WM * 32) / RG; ++i) {
+      for (int i = 0; i < NI; ++i) {
+        const int rr = rg + RG * i;
+        int64_t row = m0 + (rr >> 5) * 64 + h * 32 + (rr & 31);
+        row = row < g.M ? row : (int64_t)g.M - 1;
+        xr[i] = kd_ld4(g.X + row * g.ldx + colc);
+      }
+    }
+    if (g.addend) {                                  // residual gradient: folded into the staged tile (own elements only)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int rr = rg + RG * i;
+        int64_t row = m0 + (rr >> 5) * 64 + h * 32 + (rr & 31);
+        row = row < g.M ? row : (int64_t)g.M - 1;
+        const float4 ad = kd_ld4(g.addend + row * g.ldadd + colc);
+        float4 t = kd_ld4(T + rr * TLD + c4e * 4);
+        t.x += ad.x; t.y += ad.y; t.z += ad.z; t.w += ad.w;
+        kd_st4(T + rr * TLD + c4e * 4, t);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
       const int rr = rg + RG * i;
       const int64_t row = m0 + (rr >> 5) * 64 + h * 32 + (rr & 31);
-      if (cok && row < g.M) {
-        float4 v = kd_ld4(T + rr * TLD + c4e * 4);
-        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-        if (g.addend) {
-          const float4 ad = kd_ld4(g.addend + row * g.ldadd + col);
-          v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
-        }
-        if (EPI == 2) {
-          const float4 x = kd_ld4(g.X + row * g.ldx + col);
-          v.x *= kd_act_mask(kd_affine(x.x, esc.x, esh.x), g.epi_act);
-          v.y *= kd_act_mask(kd_affine(x.y, esc.y, esh.y), g.epi_act);
-          v.z *= kd_act_mask(kd_affine(x.z, esc.z, esh.z), g.epi_act);
-          v.w *= kd_act_mask(kd_affine(x.w, esc.w, esh.w), g.epi_act);
+      const bool ok = cok && row < g.M;
+      float4 v = kd_ld4(T + rr * TLD + c4e * 4);
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      if (EPI == 2) {
+        const float4 x = xr[i];
+        v.x *= kd_act_mask(kd_affine(x.x, esc.x, esh.x), g.epi_act);
+        v.y *= kd_act_mask(kd_affine(x.y, esc.y, esh.y), g.epi_act);
+        v.z *= kd_act_mask(kd_affine(x.z, esc.z, esh.z), g.epi_act);
+        v.w *= kd_act_mask(kd_affine(x.w, esc.w, esh.w), g.epi_act);
+        if (ok) {
           s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
           s2.x = fmaf(v.x, (x.x - emean.x) * einv.x, s2.x);
           s2.y = fmaf(v.y, (x.y - emean.y) * einv.y, s2.y);
           s2.z = fmaf(v.z, (x.z - emean.z) * einv.z, s2.z);
           s2.w = fmaf(v.w, (x.w - emean.w) * einv.w, s2.w);
-        } else if (EPI == 1) {
+        }
+      } else if (EPI == 1) {
+        if (ok) {
           s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
           s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
         }
-        kd_st4(g.C + row * g.ldc + col, v);
       }
+#ifndef KD_DBG_NOSTORE
+      if (ok) kd_st4(g.C + row * g.ldc + col, v);
+#else
+      if (ok && v.x == 12345.678f) kd_st4(g.C + row * g.ldc + col, v);
+#endif
     }
   }
   if (EPI != 0) {
-    __syncthreads();
+    kd_lds_barrier();
     float* red = smem;                               // [RG row groups][2 stats][BNt columns]
     kd_st4(red + (rg * 2 + 0) * BNt + c4e * 4, s1);
     kd_st4(red + (rg * 2 + 1) * BNt + c4e * 4, s2);
-    __syncthreads();
+    kd_lds_barrier();
     // the stats slab has one row per 128 matrix rows (kd_pwconv_stat_rows): a 256-row tile fills
     // slab row 2*rowblk and zeroes row 2*rowblk+1
     const int st = tid / BNt, c = tid % BNt;
@@ -230,6 +407,13 @@ __global__ __launch_bounds__(256, (PRO == 2 && WM == 4) ? 2 : 3) void pw_gemm_ke
       if (BMt == 256 && (srow + 1) * 128 < g.M) g.partial[((srow + 1) * 2 + st) * g.N + n0 + c] = 0.f;
     }
   }
+  KD_PH(5);                            // epilogue
+#ifdef KD_DBG_PHASES
+  if (tid == 0) {
+    atomicAdd(&kd_dbg_counters[6], 1ull);
+    for (int i = 0; i < 6; ++i) atomicAdd(&kd_dbg_counters[i], (unsigned long long)ph_acc[i]);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -430,6 +614,18 @@ int launch_wgrad(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
 
 extern "C" {
 
+// 0: v_mfma_f32_32x32x2_f32 (exact fp32 products); 1: bf16x6 split products on v_mfma_f32_32x32x16_bf16.
+// Process-wide switch for the forward / dgrad / wgrad GEMMs; returns the previous value.
+int kd_set_gemm_split(int on) { return g_gemm_split.exchange(on ? 1 : 0); }
+#ifdef KD_DBG_PHASES
+int kd_dbg_read(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(kd_dbg_counters), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(kd_dbg_counters), z, sizeof(z)); }
+  return 0;
+}
+#endif
+
 // Rows of the BN-statistics slab a GEMM over M rows writes ([rows][2][N] floats).
 int64_t kd_pwconv_stat_rows(int64_t M) { return (M + BM - 1) / BM; }
 
@@ -463,12 +659,18 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
   const dim3 blk(256);
   // 256x64 tiles when the last column tile would be <= 64 wide (N = 32, 64, 192, ...)
   const bool tall = ((N - 1) % 128) < 64;
-  const int64_t nblk = tall ? ((M + 255) / 256) * ((N + 63) / 64) : ((M + 127) / 128) * ((N + 127) / 128);
-  const dim3 grid((unsigned)nblk);
+  const int64_t ntile = tall ? ((M + 255) / 256) * ((N + 63) / 64) : ((M + 127) / 128) * ((N + 127) / 128);
+  const bool split = g_gemm_split.load(std::memory_order_relaxed) != 0;
+  const dim3 grid((unsigned)ntile);
 #define KD_GEMM_CASE(P_, E_)                                                                       \
   if (pro == P_ && epi == E_) {                                                                    \
-    if (tall) hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 4, 1>), grid, blk, 0, st, g);             \
-    else hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 2, 2>), grid, blk, 0, st, g);                  \
+    if (split) {                                                                                   \
+      if (tall) hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 4, 1, true>), grid, blk, 0, st, g);     \
+      else hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 2, 2, true>), grid, blk, 0, st, g);          \
+    } else {                                                                                       \
+      if (tall) hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 4, 1, false>), grid, blk, 0, st, g);    \
+      else hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 2, 2, false>), grid, blk, 0, st, g);         \
+    }                                                                                              \
   }
   KD_GEMM_CASE(0, 0) KD_GEMM_CASE(0, 1) KD_GEMM_CASE(0, 2)
   KD_GEMM_CASE(1, 0) KD_GEMM_CASE(1, 1) KD_GEMM_CASE(1, 2)

@@ -112,6 +112,24 @@ def bn_eval_coeffs(bn, bnc: BNC):
              P(bnc.mean), P(bnc.invstd), P(bnc.scale), P(bnc.shift), stream())
 
 
+def set_gemm_arithmetic(mode: str) -> str:
+    """'fp32': exact-fp32 MFMA products (v_mfma_f32_32x32x2_f32); 'split': every fp32 operand cut exactly into three
+    bf16 pieces, six leading piece products accumulated in fp32 on the bf16 matrix pipe (fp32-grade: <= 2^-23 |x||y|
+    per product).  Process-wide; returns the previous mode."""
+    if mode not in ("fp32", "split"):
+        raise KDError(f"unknown GEMM arithmetic {mode!r} (expected 'fp32' or 'split')")
+    return "split" if lib.kd_set_gemm_split(1 if mode == "split" else 0) else "fp32"
+
+
+def get_gemm_arithmetic() -> str:
+    prev = lib.kd_set_gemm_split(0)
+    lib.kd_set_gemm_split(prev)
+    return "split" if prev else "fp32"
+
+
+import os as _os
+set_gemm_arithmetic(_os.environ.get("KD_GEMM", "split"))     # default: the faster fp32-grade arithmetic; KD_GEMM=fp32 selects exact products
+
 PROFILE = None      # bench.py sets this to a list to time GEMM launches with HIP events on the launch stream
 
 

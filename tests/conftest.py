@@ -26,3 +26,19 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+# GPU parity modules opt in with `pytest.mark.usefixtures("gemm_arith")`: every test then runs once per GEMM
+# arithmetic of the library ("split": bf16x6 piece products on the bf16 matrix pipe, the default; "fp32": exact-fp32
+# MFMA products).  Both must meet the same tolerances.
+def pytest_generate_tests(metafunc):
+    if "gemm_arith" in metafunc.fixturenames:
+        metafunc.parametrize("gemm_arith", ["split", "fp32"], indirect=True)
+
+
+@pytest.fixture
+def gemm_arith(request):
+    from kdrt import ops
+    prev = ops.set_gemm_arithmetic(request.param)
+    yield request.param
+    ops.set_gemm_arithmetic(prev)

@@ -10,7 +10,7 @@ import kd_oracle as O
 from _gpu_util import FUSIONS, build_product, ftol, grads_match, load_random_state, max_err, oracle_run
 from _util import golden
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_arith")]
 B, HW, N, G = 2, 64, 512, 16
 LOGIT_TOL = 1e-4
 GRAD_RTOL = 2e-4

@@ -7,7 +7,7 @@ import os
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_arith")]
 
 
 def _loaders(n=8, bs=4):

@@ -9,7 +9,7 @@ import torch
 import kd_oracle as O
 from _gpu_util import max_err
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_arith")]
 TOL = 2e-5          # relative to each tensor's max magnitude
 
 
@@ -160,7 +160,9 @@ def test_fusion_and_head_small(fusion):
     head = SameResolutionSegmentationHead(256 if fusion == "concat" else 128, 2)
     stf, sth = _rand_state(fus, 41), _rand_state(head, 42)
     fus, head = fus.cuda().train(), head.cuda().train()
-    g = torch.Generator().manual_seed(6)
+    # data seed 7: with seed 6 the split arithmetic lands one pre-activation on the other side of a ReLU kink
+    # (tests/gpu_diag_flip.py: seeds 7..13 agree to <= 1.6e-6 in both arithmetics, seed 6 flips under "split" only)
+    g = torch.Generator().manual_seed(7)
     cam, lid = torch.randn(2, 128, 10, 10, generator=g), torch.randn(2, 128, 10, 10, generator=g).clamp_min(0)
     cg, lg = cam.clone().cuda().requires_grad_(True), lid.clone().cuda().requires_grad_(True)
     cc, lc = cam.clone().requires_grad_(True), lid.clone().requires_grad_(True)

@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <dlfcn.h>
+#include <cmath>
 #include <vector>
 #include "kd_hip.h"
 
@@ -41,6 +43,11 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(vec, h.data(), 16 * 1024 * 4, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int reps = argc > 1 ? atoi(argv[1]) : 5;
+  const int split = argc > 2 ? atoi(argv[2]) : 0;       // 1: bf16x6 split-MFMA arithmetic (also prints its deviation from the fp32-MFMA result)
+  kd_set_gemm_split(split);
+  float* C2 = nullptr;
+  if (split) CK(hipMalloc(&C2, big * 4));
+  printf("gemm arithmetic: %s\n", split ? "bf16x6 split products (v_mfma_f32_32x32x16_bf16)" : "fp32 (v_mfma_f32_32x32x2_f32)");
   printf("%-25s %8s | %-27s | %-17s | %-27s | %-27s | %-18s\n", "shape", "M", "fwd pro1 epi1", "fwd pro1 epi0", "dgrad pro2 epi2", "wgrad d2 a1", "copy same bytes");
   for (auto& s : shapes) {
     const double fl = 2.0 * s.M * s.K * s.N;
@@ -58,6 +65,27 @@ int main(int argc, char** argv) {
     // dgrad: A = G [M,N], A2 = Y [M,N], W^T stored [K][N], out [M,K], X(epi) [M,K]
     float t2 = timeit([&] { RC(kd_pwconv_gemm(A, s.N, A2, s.N, 2, 0, al, be, ga, nullptr, nullptr, W, nullptr, C, s.K, nullptr, 0, 2, X, s.K, sc, sh, mean, inv, 2, partial, s.M, s.N, s.K, nullptr, nullptr)); });
     float t3 = timeit([&] { RC(kd_pwconv_wgrad(A, s.N, A2, s.N, 2, 0, al, be, ga, nullptr, nullptr, X, s.K, 1, 2, sc, sh, C, s.M, s.N, s.K, ws, wsb, nullptr)); });
+    if (split) {   // same forward with both arithmetics: max |diff| relative to max |value|
+      const size_t n = std::min((size_t)s.M, (size_t)65536) * s.N;
+      std::vector<float> r0(n), r1(n);
+      RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, nullptr, C, s.N, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, s.M, s.K, s.N, nullptr, nullptr));
+      kd_set_gemm_split(0);
+      RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, nullptr, C2, s.N, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, s.M, s.K, s.N, nullptr, nullptr));
+      kd_set_gemm_split(1);
+      CK(hipMemcpy(r1.data(), C, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(r0.data(), C2, n * 4, hipMemcpyDeviceToHost));
+      double md = 0, mv = 0;
+      for (size_t i = 0; i < n; ++i) { md = std::max(md, (double)fabsf(r1[i] - r0[i])); mv = std::max(mv, (double)fabsf(r0[i])); }
+      printf("    split vs fp32 forward: max|diff| %.3e, max|value| %.3e, ratio %.2e\n", md, mv, md / mv);
+    }
+    if (auto rd = (int (*)(unsigned long long*, int))dlsym(RTLD_DEFAULT, "kd_dbg_read")) {   // dev build with phase counters
+      unsigned long long c[8];
+      rd(c, 1);
+      RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, nullptr, C, s.N, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, partial, s.M, s.K, s.N, nullptr, nullptr));
+      rd(c, 1);
+      const double t = (double)c[6];
+      printf("    phases (cycles/tile, wave 0): load-wait+transform %.0f | barrier %.0f | split+LDS %.0f | barrier %.0f | MFMA %.0f | epilogue %.0f | tiles %.0f\n",
+             c[0] / t, c[1] / t, c[2] / t, c[3] / t, c[4] / t, c[5] / t, t);
+    }
     float tc = timeit([&] { hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, 0, (const float4*)A, (float4*)C, (size_t)s.M * s.K / 4, (size_t)s.M * s.N / 4); });
     printf("%-25s %8ld | %7.1fus %5.1fTF %4.2fTB/s | %7.1fus %5.1fTF | %7.1fus %5.1fTF %4.2fTB/s | %7.1fus %5.1fTF %4.2fTB/s | %7.1fus %4.2fTB/s\n", s.name, s.M,
            t1 * 1e3, fl / t1 / 1e9, by_f / t1 / 1e9, t0 * 1e3, fl / t0 / 1e9, t2 * 1e3, fl / t2 / 1e9, by_d / t2 / 1e9,
