@@ -431,15 +431,39 @@ struct WgradArgs {
   int rows_per_split;                 // multiple of the chunk height
 };
 
-template <int WN, int WK, int WM, int DMODE, int AMODE>
-__global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs g) {
-  constexpr int TN = 64 * WN, TK = 64 * WK, CH = 32 * WM;
+//
+// SPLIT (same arithmetic as pw_gemm_kernel<.., SPLIT>): the reduction index of this GEMM is the matrix ROW m, so the
+// MFMA operands are COLUMNS of the staged tiles.  The bf16 planes stay row-major [m][n] in LDS (8-byte stores, as
+// loaded) and the fragments are fetched with ds_read_b64_tr_b16, gfx950's transposing LDS read: a 16-lane group reads
+// a 4-row x 16-column block and each lane receives one column of it -- four consecutive m for its n.  Rows are padded
+// by 32 bf16 so that the four 64-byte row segments of a block fall in four different bank quarters.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ bf16x8 kd_tr_frag(const unsigned short* plane, int ld, int row0, int col0, int lane) {
+  // fragment of the 32(col) x 16(row) operand block at (row0, col0): lane (r = lane & 31, h = lane >> 5) gets rows
+  // row0 + 8h .. +7 of column col0 + r
+  const int grp = lane >> 4, li = lane & 15;
+  const unsigned short* p0 = plane + (row0 + 8 * (grp >> 1) + (li >> 2)) * ld + col0 + 16 * (grp & 1) + 4 * (li & 3);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * ld));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int WN, int WK, int WM, int DMODE, int AMODE, bool SPLIT>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs g) {
+  constexpr int KS = WM == 1 ? 2 : 1;                           // SPLIT: 16-row MFMA steps per wave per chunk
+  constexpr int TN = 64 * WN, TK = 64 * WK, CH = SPLIT ? 16 * WM * KS : 32 * WM;
   constexpr int DF4 = CH * TN / 1024, AF4 = CH * TK / 1024;     // float4 per thread per chunk
-  constexpr int SMEM = CH * (TN + TK);
+  constexpr int LDN = TN + 32, LDK = TK + 32;                   // SPLIT: bf16 per LDS row
+  constexpr int SMEM = SPLIT ? 3 * CH * (LDN + LDK) / 2 : CH * (TN + TK);
   static_assert((WM - 1) * WN * WK * 4096 <= SMEM, "cross-wave reduction must fit the staging LDS");
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
   float* Ds = smem;
   float* As = smem + CH * TN;
+  unsigned short* Dh = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Ah = Dh + 3 * CH * LDN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / (WN * WK), wn = (wave % (WN * WK)) / WK, wk = wave % WK;
   const int ntn = (g.N + TN - 1) / TN, ntk = (g.K + TK - 1) / TK;
@@ -512,19 +536,64 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs g) {
   if (mbeg < mend) load_chunk(mbeg);
   for (int64_t mc = mbeg; mc < mend; mc += CH) {
     transform(mc);
-    __syncthreads();
+    kd_lds_barrier();
+    if (SPLIT) {
 #pragma unroll
-    for (int i = 0; i < DF4; ++i) {
-      const int idx = tid + 256 * i;
-      kd_st4(Ds + (idx / (TN / 4)) * TN + (idx % (TN / 4)) * 4, rd[i]);
-    }
+      for (int i = 0; i < DF4; ++i) {
+        const int idx = tid + 256 * i;
+        uint2 hi, mid, lo;
+        kd_split3(rd[i], hi, mid, lo);
+        unsigned short* d = Dh + (idx / (TN / 4)) * LDN + (idx % (TN / 4)) * 4;
+        *reinterpret_cast<uint2*>(d) = hi;
+        *reinterpret_cast<uint2*>(d + CH * LDN) = mid;
+        *reinterpret_cast<uint2*>(d + 2 * CH * LDN) = lo;
+      }
 #pragma unroll
-    for (int i = 0; i < AF4; ++i) {
-      const int idx = tid + 256 * i;
-      kd_st4(As + (idx / (TK / 4)) * TK + (idx % (TK / 4)) * 4, ra[i]);
+      for (int i = 0; i < AF4; ++i) {
+        const int idx = tid + 256 * i;
+        uint2 hi, mid, lo;
+        kd_split3(ra[i], hi, mid, lo);
+        unsigned short* d = Ah + (idx / (TK / 4)) * LDK + (idx % (TK / 4)) * 4;
+        *reinterpret_cast<uint2*>(d) = hi;
+        *reinterpret_cast<uint2*>(d + CH * LDK) = mid;
+        *reinterpret_cast<uint2*>(d + 2 * CH * LDK) = lo;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < DF4; ++i) {
+        const int idx = tid + 256 * i;
+        kd_st4(Ds + (idx / (TN / 4)) * TN + (idx % (TN / 4)) * 4, rd[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < AF4; ++i) {
+        const int idx = tid + 256 * i;
+        kd_st4(As + (idx / (TK / 4)) * TK + (idx % (TK / 4)) * 4, ra[i]);
+      }
     }
-    __syncthreads();
+    kd_lds_barrier();
     if (mc + CH < mend) load_chunk(mc + CH);
+    if (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int mrow = (wm * KS + ks) * 16;
+        bf16x8 d[2][3], a[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            d[i][p] = kd_tr_frag(Dh + p * CH * LDN, LDN, mrow, wn * 64 + i * 32, lane);
+            a[i][p] = kd_tr_frag(Ah + p * CH * LDK, LDK, mrow, wk * 64 + i * 32, lane);
+          }
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ki = 0; ki < 2; ++ki)
+              acc[ni][ki] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d[ni][PA[t]], a[ki][PB[t]], acc[ni][ki], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int m = wm * 32 + 2 * s + (lane >> 5);
@@ -543,7 +612,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs g) {
   }
 
   if (WM > 1) {                                   // sum the WM row-slices of this tile through LDS
-    __syncthreads();
+    kd_lds_barrier();
     if (wm > 0) {
       float* dst = smem + (((wm - 1) * WN + wn) * WK + wk) * 4096;
 #pragma unroll
@@ -553,7 +622,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs g) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) dst[((ni * 2 + ki) * 16 + r) * 64 + lane] = acc[ni][ki][r];
     }
-    __syncthreads();
+    kd_lds_barrier();
     if (wm == 0) {
       for (int o = 1; o < WM; ++o) {
         const float* src = smem + (((o - 1) * WN + wn) * WK + wk) * 4096;
@@ -588,9 +657,9 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
   if (i < R * Cc) out[(int64_t)(i % Cc) * R + i / Cc] = in[i];
 }
 
-template <int WN, int WK, int WM>
+template <int WN, int WK, int WM, bool SPLIT>
 int launch_wgrad(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
-  constexpr int TN = 64 * WN, TK = 64 * WK, CH = 32 * WM;
+  constexpr int TN = 64 * WN, TK = 64 * WK, CH = SPLIT ? 16 * WM * (WM == 1 ? 2 : 1) : 32 * WM;
   const int ntiles = ((g.N + TN - 1) / TN) * ((g.K + TK - 1) / TK);
   int nsplit = (512 + ntiles - 1) / ntiles;
   int64_t chunks = (g.M + CH - 1) / CH;
@@ -603,10 +672,10 @@ int launch_wgrad(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
   g.rows_per_split = (int)(cps * CH);
   nsplit = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
   const dim3 grid(ntiles * nsplit), blk(256);
-  if (g.d_mode == 2 && g.a_mode == 1) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 1>), grid, blk, 0, st, g);
-  else if (g.d_mode == 2) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 0>), grid, blk, 0, st, g);
-  else if (g.a_mode == 1) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 0, 1>), grid, blk, 0, st, g);
-  else hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 0, 0>), grid, blk, 0, st, g);
+  if (g.d_mode == 2 && g.a_mode == 1) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 1, SPLIT>), grid, blk, 0, st, g);
+  else if (g.d_mode == 2) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 0, SPLIT>), grid, blk, 0, st, g);
+  else if (g.a_mode == 1) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 0, 1, SPLIT>), grid, blk, 0, st, g);
+  else hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 0, 0, SPLIT>), grid, blk, 0, st, g);
   return kd_slab_reduce_launch(g.slab, nsplit, (int64_t)g.N * g.K, dW, st);
 }
 
@@ -702,10 +771,16 @@ int kd_pwconv_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, in
   WgradArgs g{D, ldd, X, ldx, al, be, ga, msc, msh, d_mode, d_act, A, lda, asc, ash, a_mode, a_act, (float*)ws,
               (int)M, N, K, 0};
   hipStream_t st = (hipStream_t)stream;
-  if (N > 64 && K > 64) return launch_wgrad<2, 2, 1>(g, ws_bytes, dW, st);
-  if (N > 64) return launch_wgrad<2, 1, 2>(g, ws_bytes, dW, st);
-  if (K > 64) return launch_wgrad<1, 2, 2>(g, ws_bytes, dW, st);
-  return launch_wgrad<1, 1, 4>(g, ws_bytes, dW, st);
+  if (g_gemm_split.load(std::memory_order_relaxed)) {
+    if (N > 64 && K > 64) return launch_wgrad<2, 2, 1, true>(g, ws_bytes, dW, st);
+    if (N > 64) return launch_wgrad<2, 1, 2, true>(g, ws_bytes, dW, st);
+    if (K > 64) return launch_wgrad<1, 2, 2, true>(g, ws_bytes, dW, st);
+    return launch_wgrad<1, 1, 4, true>(g, ws_bytes, dW, st);
+  }
+  if (N > 64 && K > 64) return launch_wgrad<2, 2, 1, false>(g, ws_bytes, dW, st);
+  if (N > 64) return launch_wgrad<2, 1, 2, false>(g, ws_bytes, dW, st);
+  if (K > 64) return launch_wgrad<1, 2, 2, false>(g, ws_bytes, dW, st);
+  return launch_wgrad<1, 1, 4, false>(g, ws_bytes, dW, st);
 }
 
 // out[c][r] = in[r][c] -- used once per step per weight to get W^T for the dgrad GEMM.
