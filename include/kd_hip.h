@@ -105,10 +105,28 @@ int kd_bn_bwd_finalize(float* partial, int rows, int C, int pstride, int64_t cou
                        float* ga, float* dbias, void* stream);
 
 /* ---- LiDAR branch (lidar_encoder.py:25-35,42-99) ----------------------------------------------- */
+/* layer 0 (Conv1d 4 -> C, bias): y == NULL runs the BatchNorm-statistics pass only -- the consumers below recompute
+ * the layer from the 16-byte point, so its [P, C] output never exists in HBM */
 int kd_lidar_l0_fwd(const float* pts, const float* w, const float* b, float* y, float* partial, int64_t P, int C,
                     const int* p_dev, void* stream);
+/* layer 1 (Conv1d C0 -> N, lidar_encoder.py:29) over act0(bn0(layer0(pts))) recomputed on load: forward (epi 0 store,
+ * 1 store + BN statistics), data gradient (writes G0 = d/d(layer-0 output) * act0' with the BN0-backward sums; Wt = W1
+ * transposed to [K0][N1]) and weight gradient.  Same kernels and coefficient conventions as kd_pwconv_gemm / _wgrad. */
+int kd_lidar_l1_fwd(const float* pts, const float* w0, const float* b0, const float* sc0, const float* sh0, int act0,
+                    const float* W1, const float* bias1, float* C, int64_t ldc, int epi, float* partial, int64_t M,
+                    int K, int N, const int* m_dev, void* stream);
+int kd_lidar_l1_dgrad(const float* G, int64_t ldg, const float* Y1, int64_t ldy, const float* al, const float* be,
+                      const float* ga, const float* msc, const float* msh, int mact, const float* Wt, float* G0,
+                      int64_t ldg0, const float* pts, const float* w0, const float* b0, const float* sc0,
+                      const float* sh0, const float* mean0, const float* invstd0, int act0, float* partial,
+                      int64_t M, int N1, int K0, void* stream);
+int kd_lidar_l1_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, int d_act, const float* al,
+                      const float* be, const float* ga, const float* msc, const float* msh, const float* pts,
+                      const float* w0, const float* b0, const float* sc0, const float* sh0, int act0, float* dW,
+                      int64_t M, int N, int K, void* ws, size_t ws_bytes, void* stream);
 size_t kd_lidar_l0_bwd_ws_bytes(int64_t P, int C);
-int kd_lidar_l0_bwd(const float* D, const float* Y, const float* al, const float* be, const float* ga,
+/* Y == NULL: the layer output is recomputed from (w, b) and the point (it was never written, see kd_lidar_l1_*) */
+int kd_lidar_l0_bwd(const float* D, const float* Y, const float* w, const float* b, const float* al, const float* be, const float* ga,
                     const float* pts, float* dwb, int64_t P, int C, void* ws, size_t ws_bytes, void* stream);
 int kd_lidar_scatter_max_fwd(const float* pts, const float* y, const float* sc, const float* sh, int act,
                              float* grid, int B, int64_t N, int C, int H, int W, float x0, float x1, float y0,

@@ -90,6 +90,16 @@ __device__ __forceinline__ void kd_lds_barrier() { __syncthreads(); }
 __device__ __forceinline__ void kd_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
 
+// LiDAR point-MLP layer 0 (Conv1d 4 -> C, lidar_encoder.py:26): ONE evaluation order, used by the statistics pass and
+// by every kernel that recomputes the layer from the 16-byte point instead of reading its [P, C] output from HBM, so a
+// recomputed value is bit-identical to the one the BatchNorm statistics were taken over.
+__device__ __forceinline__ float kd_l0_raw(float4 pt, float4 w, float b) {
+  return fmaf(w.w, pt.w, fmaf(w.z, pt.z, fmaf(w.y, pt.y, fmaf(w.x, pt.x, b))));
+}
+__device__ __forceinline__ float4 kd_l0_raw4(float4 pt, const float4 (&w)[4], float4 b) {
+  return make_float4(kd_l0_raw(pt, w[0], b.x), kd_l0_raw(pt, w[1], b.y), kd_l0_raw(pt, w[2], b.z), kd_l0_raw(pt, w[3], b.w));
+}
+
 __device__ __forceinline__ float kd_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

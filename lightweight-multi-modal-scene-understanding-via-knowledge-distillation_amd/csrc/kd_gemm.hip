@@ -51,6 +51,7 @@ struct GemmArgs {
   float* partial;                     // EPI1/2: [rowblocks][2][N]
   int M, K, N;
   const int* m_dev;                   // optional: device-side row count (<= M); rows beyond it are skipped
+  const float* l0w; const float* l0b; // PRO3 / EPI3: LiDAR layer-0 weight [C0][4] and bias [C0] (A or X = points [M,4])
 };
 
 // Tile shape: WM x WN waves of 64x64 each (WM*WN == 4): 128x128 for wide outputs, 256x64 when the
@@ -137,18 +138,24 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
   // MFMAs of the previous tile.  Per-channel coefficients depend only on (k0, tid & 7).
   // PF2: a second register stage for the operand tiles (split arithmetic, 128x128 tile, PRO 0/1): the matrix work
   // of one K-tile (~0.6 us) is shorter than the HBM latency under load, so two K-tiles of loads are kept in flight.
-  constexpr bool PF2 = SPLIT && PRO != 2 && WM == 2;
+  constexpr bool PF2 = SPLIT && PRO < 2 && WM == 2;
   // Per-channel coefficients travel WITH their tile (loaded just before it): a coefficient load issued later than
   // a prefetch would sit behind it in the in-order vmcnt queue and drain the prefetch when first used.  Only the
   // fp32 PRO2 kernel (170-register budget at 3 workgroups/CU) fetches its five vectors at the point of use.
-  constexpr int NCO = PRO == 2 ? 5 : 2;
+  // PRO3 (A = act(bn(layer0(point)))): sc, sh, the four weight rows and the bias of the thread's 4 channels
+  constexpr int NCO = PRO == 2 ? 5 : (PRO == 3 ? 7 : 2);
   constexpr bool CO_LATE = PRO == 2 && !SPLIT;
-  float4 ra0[AF], rb0[BF], ra1[PF2 ? AF : 1], rb1[PF2 ? BF : 1], rx[PRO == 2 ? AF : 1], co0[NCO], co1[PF2 ? NCO : 1];
+  float4 ra0[AF], rb0[BF], ra1[PF2 ? AF : 1], rb1[PF2 ? BF : 1], rx[PRO >= 2 ? AF : 1], co0[NCO], co1[PF2 ? NCO : 1];
   const int c4 = tid & 7;
   auto issue_loads = [&](int kt, float4 (&ra)[AF], float4 (&rb)[BF], float4 (&co)[NCO]) {
     int gk = kt * BK + c4 * 4;
     gk = gk < g.K ? gk : g.K - 4;
-    if (PRO == 1) { co[0] = kd_ld4(g.p0 + gk); co[1] = kd_ld4(g.p1 + gk); }
+    if (PRO == 1 || PRO == 3) { co[0] = kd_ld4(g.p0 + gk); co[1] = kd_ld4(g.p1 + gk); }
+    if (PRO == 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) co[2 + j] = kd_ld4(g.l0w + (gk + j) * 4);
+      co[6] = kd_ld4(g.l0b + gk);
+    }
     if (PRO == 2 && !CO_LATE) {
       co[0] = kd_ld4(g.p0 + gk); co[1] = kd_ld4(g.p1 + gk); co[2] = kd_ld4(g.p2 + gk); co[3] = kd_ld4(g.p3 + gk); co[4] = kd_ld4(g.p4 + gk);
     }
@@ -159,8 +166,12 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
 #ifdef KD_DBG_NOLDG
       gm = (tid >> 3) + 32 * i;
 #endif
-      ra[i] = kd_ld4(g.A + gm * g.lda + gk);
-      if (PRO == 2) rx[i] = kd_ld4(g.A2 + gm * g.lda2 + gk);
+      if (PRO == 3) {
+        if (kt == 0) rx[i] = kd_ld4(g.A + gm * 4);      // the point: the same row for every K-tile
+      } else {
+        ra[i] = kd_ld4(g.A + gm * g.lda + gk);
+        if (PRO == 2) rx[i] = kd_ld4(g.A2 + gm * g.lda2 + gk);
+      }
     }
 #pragma unroll
     for (int i = 0; i < BF; ++i) {
@@ -181,6 +192,9 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
       float4 va = ra[i];
       if (PRO == 1) {
         va = kd_affine_act4(va, co[0], co[1], g.pro_act);
+      } else if (PRO == 3) {
+        const float4 wr[4] = {co[2], co[3], co[4], co[5]};
+        va = kd_affine_act4(kd_l0_raw4(rx[i], wr, co[6]), co[0], co[1], g.pro_act);
       } else if (PRO == 2) {
         const float4 x = rx[i];
         va.x = kd_bwd_operand(va.x, x.x, co[0].x, co[1].x, co[2].x, co[3].x, co[4].x, g.pro_act);
@@ -315,7 +329,13 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
     const float4 bv = kd_ld4(bp + (g.bias ? colc : 0));
     const bool hb = g.bias != nullptr;
     bias4 = make_float4(hb ? bv.x : 0.f, hb ? bv.y : 0.f, hb ? bv.z : 0.f, hb ? bv.w : 0.f);
-    if (EPI == 2) { esc = kd_ld4(g.esc + colc); esh = kd_ld4(g.esh + colc); emean = kd_ld4(g.emean + colc); einv = kd_ld4(g.einv + colc); }
+    if (EPI >= 2) { esc = kd_ld4(g.esc + colc); esh = kd_ld4(g.esh + colc); emean = kd_ld4(g.emean + colc); einv = kd_ld4(g.einv + colc); }
+  }
+  float4 ew[EPI == 3 ? 4 : 1], eb = kd_zero4();      // EPI3: X is layer 0 of the point, recomputed for the thread's 4 columns
+  if (EPI == 3) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ew[j] = kd_ld4(g.l0w + (colc + j) * 4);
+    eb = kd_ld4(g.l0b + colc);
   }
   float4 s1 = kd_zero4(), s2 = kd_zero4();
   constexpr int NI = (WM * 32) / RG;                   // rows per thread per half
@@ -334,14 +354,14 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
     KD_PHE(2);
     // All global LOADS of this half are issued before its first store (clamped addresses, no branches), so no
     // wait on a load ever has an older store in front of it in the in-order vmcnt queue.
-    float4 xr[EPI == 2 ? NI : 1];
-    if (EPI == 2) {
+    float4 xr[EPI >= 2 ? NI : 1];
+    if (EPI >= 2) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int rr = rg + RG * i;
         int64_t row = m0 + (rr >> 5) * 64 + h * 32 + (rr & 31);
         row = row < g.M ? row : (int64_t)g.M - 1;
-        xr[i] = kd_ld4(g.X + row * g.ldx + colc);
+        xr[i] = EPI == 3 ? kd_ld4(g.X + row * 4) : kd_ld4(g.X + row * g.ldx + colc);
       }
     }
     if (g.addend) {                                  // residual gradient: folded into the staged tile (own elements only)
@@ -363,8 +383,9 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
       const bool ok = cok && row < g.M;
       float4 v = kd_ld4(T + rr * TLD + c4e * 4);
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-      if (EPI == 2) {
-        const float4 x = xr[i];
+      if (EPI >= 2) {
+        float4 x = xr[i];
+        if constexpr (EPI == 3) x = kd_l0_raw4(xr[i], ew, eb);
         v.x *= kd_act_mask(kd_affine(x.x, esc.x, esh.x), g.epi_act);
         v.y *= kd_act_mask(kd_affine(x.y, esc.y, esh.y), g.epi_act);
         v.z *= kd_act_mask(kd_affine(x.z, esc.z, esh.z), g.epi_act);
@@ -429,6 +450,7 @@ struct WgradArgs {
   float* slab;                        // [nsplit][N][K]
   int M, N, K;
   int rows_per_split;                 // multiple of the chunk height
+  const float* l0w; const float* l0b; // AMODE 2: A = act(bn(layer0(point))), g.A = points [M,4]
 };
 
 //
@@ -489,12 +511,17 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs 
   const int gn = n0 + dc4 * 4, gk = k0 + ac4 * 4;
   const bool nok = gn < g.N, kok = gk < g.K;
   const int gnc = nok ? gn : g.N - 4, gkc = kok ? gk : g.K - 4;
-  float4 cd[DMODE == 2 ? 5 : 1], ca[AMODE == 1 ? 2 : 1], rx[DMODE == 2 ? DF4 : 1];
+  float4 cd[DMODE == 2 ? 5 : 1], ca[AMODE >= 1 ? 2 : 1], rx[DMODE == 2 ? DF4 : 1], cw[AMODE == 2 ? 4 : 1], cb = kd_zero4();
   if (DMODE == 2) {
     cd[0] = kd_ld4(g.al + gnc); cd[1] = kd_ld4(g.be + gnc); cd[2] = kd_ld4(g.ga + gnc);
     cd[3] = kd_ld4(g.msc + gnc); cd[4] = kd_ld4(g.msh + gnc);
   }
-  if (AMODE == 1) { ca[0] = kd_ld4(g.asc + gkc); ca[1] = kd_ld4(g.ash + gkc); }
+  if (AMODE >= 1) { ca[0] = kd_ld4(g.asc + gkc); ca[1] = kd_ld4(g.ash + gkc); }
+  if (AMODE == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cw[j] = kd_ld4(g.l0w + (gkc + j) * 4);
+    cb = kd_ld4(g.l0b + gkc);
+  }
   auto load_chunk = [&](int64_t mc) {
 #pragma unroll
     for (int i = 0; i < DF4; ++i) {
@@ -507,7 +534,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs 
     for (int i = 0; i < AF4; ++i) {
       int64_t gm = mc + (tid + 256 * i) / (TK / 4);
       gm = gm < mend ? gm : mend - 1;
-      ra[i] = kd_ld4(g.A + gm * g.lda + gkc);
+      ra[i] = AMODE == 2 ? kd_ld4(g.A + gm * 4) : kd_ld4(g.A + gm * g.lda + gkc);
     }
   };
   auto transform = [&](int64_t mc) {
@@ -528,6 +555,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs 
     for (int i = 0; i < AF4; ++i) {
       float4 v = ra[i];
       if (AMODE == 1) v = kd_affine_act4(v, ca[0], ca[1], g.a_act);
+      if constexpr (AMODE == 2) v = kd_affine_act4(kd_l0_raw4(v, cw, cb), ca[0], ca[1], g.a_act);
       const bool ok = kok && (mc + (tid + 256 * i) / (TK / 4) < mend);
       ra[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     }
@@ -672,11 +700,53 @@ int launch_wgrad(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
   g.rows_per_split = (int)(cps * CH);
   nsplit = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
   const dim3 grid(ntiles * nsplit), blk(256);
-  if (g.d_mode == 2 && g.a_mode == 1) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 1, SPLIT>), grid, blk, 0, st, g);
+  if (g.d_mode == 2 && g.a_mode == 2) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 2, SPLIT>), grid, blk, 0, st, g);
+  else if (g.d_mode == 2 && g.a_mode == 1) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 1, SPLIT>), grid, blk, 0, st, g);
   else if (g.d_mode == 2) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 0, SPLIT>), grid, blk, 0, st, g);
   else if (g.a_mode == 1) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 0, 1, SPLIT>), grid, blk, 0, st, g);
   else hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 0, 0, SPLIT>), grid, blk, 0, st, g);
   return kd_slab_reduce_launch(g.slab, nsplit, (int64_t)g.N * g.K, dW, st);
+}
+
+
+int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {
+  const dim3 blk(256);
+  // 256x64 tiles when the last column tile would be <= 64 wide (N = 32, 64, 192, ...)
+  const bool tall = ((g.N - 1) % 128) < 64;
+  const int64_t M = g.M;
+  const int64_t ntile = tall ? ((M + 255) / 256) * ((g.N + 63) / 64) : ((M + 127) / 128) * ((g.N + 127) / 128);
+  const bool split = g_gemm_split.load(std::memory_order_relaxed) != 0;
+  const dim3 grid((unsigned)ntile);
+#define KD_GEMM_CASE(P_, E_)                                                                       \
+  if (pro == P_ && epi == E_) {                                                                    \
+    if (split) {                                                                                   \
+      if (tall) hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 4, 1, true>), grid, blk, 0, st, g);     \
+      else hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 2, 2, true>), grid, blk, 0, st, g);          \
+    } else {                                                                                       \
+      if (tall) hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 4, 1, false>), grid, blk, 0, st, g);    \
+      else hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 2, 2, false>), grid, blk, 0, st, g);         \
+    }                                                                                              \
+  }
+  KD_GEMM_CASE(0, 0) KD_GEMM_CASE(0, 1) KD_GEMM_CASE(0, 2)
+  KD_GEMM_CASE(1, 0) KD_GEMM_CASE(1, 1) KD_GEMM_CASE(1, 2)
+  KD_GEMM_CASE(2, 0) KD_GEMM_CASE(2, 1) KD_GEMM_CASE(2, 2)
+  KD_GEMM_CASE(3, 0) KD_GEMM_CASE(3, 1) KD_GEMM_CASE(2, 3)      // LiDAR layer 0 recomputed from the points
+#undef KD_GEMM_CASE
+  return kd_check_launch("kd_pwconv_gemm");
+}
+
+int wgrad_launch(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
+  const int N = g.N, K = g.K;
+  if (g_gemm_split.load(std::memory_order_relaxed)) {
+    if (N > 64 && K > 64) return launch_wgrad<2, 2, 1, true>(g, ws_bytes, dW, st);
+    if (N > 64) return launch_wgrad<2, 1, 2, true>(g, ws_bytes, dW, st);
+    if (K > 64) return launch_wgrad<1, 2, 2, true>(g, ws_bytes, dW, st);
+    return launch_wgrad<1, 1, 4, true>(g, ws_bytes, dW, st);
+  }
+  if (N > 64 && K > 64) return launch_wgrad<2, 2, 1, false>(g, ws_bytes, dW, st);
+  if (N > 64) return launch_wgrad<2, 1, 2, false>(g, ws_bytes, dW, st);
+  if (K > 64) return launch_wgrad<1, 2, 2, false>(g, ws_bytes, dW, st);
+  return launch_wgrad<1, 1, 4, false>(g, ws_bytes, dW, st);
 }
 
 }  // namespace
@@ -723,29 +793,8 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
   if (pro == 2 && !p3) { p3 = p0; p4 = p0; }          // mask disabled (act none): any valid vector will do
   KD_REQUIRE(K >= 4, KD_ERR_SHAPE, "kd_pwconv_gemm: K must be >= 4");
   GemmArgs g{A, lda, A2, lda2, p0, p1, p2, p3, p4, pro, pro_act, W, bias, C, ldc, addend, ldadd,
-             X, ldx, esc, esh, emean, einv, epi_act, partial, (int)M, K, N, m_dev};
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 blk(256);
-  // 256x64 tiles when the last column tile would be <= 64 wide (N = 32, 64, 192, ...)
-  const bool tall = ((N - 1) % 128) < 64;
-  const int64_t ntile = tall ? ((M + 255) / 256) * ((N + 63) / 64) : ((M + 127) / 128) * ((N + 127) / 128);
-  const bool split = g_gemm_split.load(std::memory_order_relaxed) != 0;
-  const dim3 grid((unsigned)ntile);
-#define KD_GEMM_CASE(P_, E_)                                                                       \
-  if (pro == P_ && epi == E_) {                                                                    \
-    if (split) {                                                                                   \
-      if (tall) hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 4, 1, true>), grid, blk, 0, st, g);     \
-      else hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 2, 2, true>), grid, blk, 0, st, g);          \
-    } else {                                                                                       \
-      if (tall) hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 4, 1, false>), grid, blk, 0, st, g);    \
-      else hipLaunchKernelGGL((pw_gemm_kernel<P_, E_, 2, 2, false>), grid, blk, 0, st, g);         \
-    }                                                                                              \
-  }
-  KD_GEMM_CASE(0, 0) KD_GEMM_CASE(0, 1) KD_GEMM_CASE(0, 2)
-  KD_GEMM_CASE(1, 0) KD_GEMM_CASE(1, 1) KD_GEMM_CASE(1, 2)
-  KD_GEMM_CASE(2, 0) KD_GEMM_CASE(2, 1) KD_GEMM_CASE(2, 2)
-#undef KD_GEMM_CASE
-  return kd_check_launch("kd_pwconv_gemm");
+             X, ldx, esc, esh, emean, einv, epi_act, partial, (int)M, K, N, m_dev, nullptr, nullptr};
+  return gemm_launch(g, pro, epi, (hipStream_t)stream);
 }
 
 size_t kd_pwconv_wgrad_ws_bytes(int64_t M, int N, int K) {
@@ -769,18 +818,55 @@ int kd_pwconv_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, in
   KD_REQUIRE(M < (int64_t)1 << 31, KD_ERR_SHAPE, "kd_pwconv_wgrad: M too large");
   if (d_mode == 2 && !msc) { msc = al; msh = al; }       // mask disabled (act none): any valid vector will do
   WgradArgs g{D, ldd, X, ldx, al, be, ga, msc, msh, d_mode, d_act, A, lda, asc, ash, a_mode, a_act, (float*)ws,
-              (int)M, N, K, 0};
-  hipStream_t st = (hipStream_t)stream;
-  if (g_gemm_split.load(std::memory_order_relaxed)) {
-    if (N > 64 && K > 64) return launch_wgrad<2, 2, 1, true>(g, ws_bytes, dW, st);
-    if (N > 64) return launch_wgrad<2, 1, 2, true>(g, ws_bytes, dW, st);
-    if (K > 64) return launch_wgrad<1, 2, 2, true>(g, ws_bytes, dW, st);
-    return launch_wgrad<1, 1, 4, true>(g, ws_bytes, dW, st);
-  }
-  if (N > 64 && K > 64) return launch_wgrad<2, 2, 1, false>(g, ws_bytes, dW, st);
-  if (N > 64) return launch_wgrad<2, 1, 2, false>(g, ws_bytes, dW, st);
-  if (K > 64) return launch_wgrad<1, 2, 2, false>(g, ws_bytes, dW, st);
-  return launch_wgrad<1, 1, 4, false>(g, ws_bytes, dW, st);
+              (int)M, N, K, 0, nullptr, nullptr};
+  return wgrad_launch(g, ws_bytes, dW, (hipStream_t)stream);
+}
+
+
+// ---- LiDAR point-MLP layer 1 with layer 0 recomputed from the points (never materialised) -------------------
+// forward: C[M,N] = act0(bn0(l0(pts))) . W1^T + bias1; epi 0 store, 1 store + BN statistics
+int kd_lidar_l1_fwd(const float* pts, const float* w0, const float* b0, const float* sc0, const float* sh0, int act0,
+                    const float* W1, const float* bias1, float* C, int64_t ldc, int epi, float* partial, int64_t M,
+                    int K, int N, const int* m_dev, void* stream) {
+  KD_REQUIRE(pts && w0 && b0 && sc0 && sh0 && W1 && C && M > 0 && K >= 4 && N > 0, KD_ERR_ARG, "kd_lidar_l1_fwd: bad args");
+  KD_REQUIRE(M < (int64_t)1 << 31 && K % 4 == 0 && N % 4 == 0 && ldc % 4 == 0, KD_ERR_SHAPE, "kd_lidar_l1_fwd: K, N, ldc must be multiples of 4");
+  KD_REQUIRE(kd_aligned16(pts) && kd_aligned16(w0) && kd_aligned16(b0) && kd_aligned16(sc0) && kd_aligned16(sh0) && kd_aligned16(W1) &&
+             kd_aligned16(C) && kd_aligned16(bias1), KD_ERR_ALIGN, "kd_lidar_l1_fwd: 16-byte alignment");
+  KD_REQUIRE((epi == 0 || epi == 1) && (epi == 0 || partial), KD_ERR_ARG, "kd_lidar_l1_fwd: epi must be 0, or 1 with a statistics slab");
+  GemmArgs g{pts, 4, nullptr, 0, sc0, sh0, nullptr, nullptr, nullptr, 3, act0, W1, bias1, C, ldc, nullptr, 0,
+             nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, partial, (int)M, K, N, m_dev, w0, b0};
+  return gemm_launch(g, 3, epi, (hipStream_t)stream);
+}
+
+// data gradient: G0[M,K0] = (dy1_eff[M,N1] . W1) * act0'(bn0(l0(pts))) with the BN0-backward sums in `partial`;
+// dy1_eff = al*(G*mask(Y1*msc+msh)) + be*Y1 + ga; Wt = W1 as stored ([N1][K0]) transposed by the caller ([K0][N1]).
+int kd_lidar_l1_dgrad(const float* G, int64_t ldg, const float* Y1, int64_t ldy, const float* al, const float* be,
+                      const float* ga, const float* msc, const float* msh, int mact, const float* Wt, float* G0,
+                      int64_t ldg0, const float* pts, const float* w0, const float* b0, const float* sc0,
+                      const float* sh0, const float* mean0, const float* invstd0, int act0, float* partial,
+                      int64_t M, int N1, int K0, void* stream) {
+  KD_REQUIRE(G && Y1 && al && be && ga && Wt && G0 && pts && w0 && b0 && sc0 && sh0 && mean0 && invstd0 && partial && M > 0,
+             KD_ERR_ARG, "kd_lidar_l1_dgrad: bad args");
+  KD_REQUIRE(mact == KD_ACT_NONE || (msc && msh), KD_ERR_ARG, "kd_lidar_l1_dgrad: mask needs sc/sh");
+  KD_REQUIRE(M < (int64_t)1 << 31 && N1 % 4 == 0 && K0 % 4 == 0 && ldg % 4 == 0 && ldy % 4 == 0 && ldg0 % 4 == 0, KD_ERR_SHAPE,
+             "kd_lidar_l1_dgrad: channel counts and strides must be multiples of 4");
+  if (!msc) { msc = al; msh = al; }
+  GemmArgs g{G, ldg, Y1, ldy, al, be, ga, msc, msh, 2, mact, Wt, nullptr, G0, ldg0, nullptr, 0,
+             pts, 4, sc0, sh0, mean0, invstd0, act0, partial, (int)M, N1, K0, nullptr, w0, b0};
+  return gemm_launch(g, 2, 3, (hipStream_t)stream);
+}
+
+// weight gradient dW1[N,K] = dy1_eff[M,N]^T . act0(bn0(l0(pts)))[M,K]
+int kd_lidar_l1_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, int d_act, const float* al,
+                      const float* be, const float* ga, const float* msc, const float* msh, const float* pts,
+                      const float* w0, const float* b0, const float* sc0, const float* sh0, int act0, float* dW,
+                      int64_t M, int N, int K, void* ws, size_t ws_bytes, void* stream) {
+  KD_REQUIRE(D && X && al && be && ga && pts && w0 && b0 && sc0 && sh0 && dW && ws && M > 0, KD_ERR_ARG, "kd_lidar_l1_wgrad: bad args");
+  KD_REQUIRE(d_act == KD_ACT_NONE || (msc && msh), KD_ERR_ARG, "kd_lidar_l1_wgrad: mask needs sc/sh");
+  KD_REQUIRE(M < (int64_t)1 << 31 && N % 4 == 0 && K % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0, KD_ERR_SHAPE, "kd_lidar_l1_wgrad: N, K, ld must be multiples of 4");
+  if (!msc) { msc = al; msh = al; }
+  WgradArgs g{D, ldd, X, ldx, al, be, ga, msc, msh, 2, d_act, pts, 4, sc0, sh0, 2, act0, (float*)ws, (int)M, N, K, 0, w0, b0};
+  return wgrad_launch(g, ws_bytes, dW, (hipStream_t)stream);
 }
 
 // out[c][r] = in[r][c] -- used once per step per weight to get W^T for the dgrad GEMM.

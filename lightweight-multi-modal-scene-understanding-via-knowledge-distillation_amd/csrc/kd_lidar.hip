@@ -48,12 +48,8 @@ __global__ __launch_bounds__(256) void lidar_l0_fwd_kernel(L0Args a) {
   if (active) {
     for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < a.P; p += (int64_t)gridDim.x * a.slots) {
       const float4 pt = kd_ld4(a.pts + p * 4);
-      float4 v;
-      v.x = fmaf(wr[0].w, pt.w, fmaf(wr[0].z, pt.z, fmaf(wr[0].y, pt.y, fmaf(wr[0].x, pt.x, bias.x))));
-      v.y = fmaf(wr[1].w, pt.w, fmaf(wr[1].z, pt.z, fmaf(wr[1].y, pt.y, fmaf(wr[1].x, pt.x, bias.y))));
-      v.z = fmaf(wr[2].w, pt.w, fmaf(wr[2].z, pt.z, fmaf(wr[2].y, pt.y, fmaf(wr[2].x, pt.x, bias.z))));
-      v.w = fmaf(wr[3].w, pt.w, fmaf(wr[3].z, pt.z, fmaf(wr[3].y, pt.y, fmaf(wr[3].x, pt.x, bias.w))));
-      kd_st4(a.y + p * a.C + c0, v);
+      const float4 v = kd_l0_raw4(pt, wr, bias);
+      if (a.y) kd_st4(a.y + p * a.C + c0, v);          // y == NULL: statistics only, consumers recompute the layer
       s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
       s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
     }
@@ -76,6 +72,7 @@ struct L0BwdArgs {
   const float* D; const float* Y; const float* al; const float* be; const float* ga;
   const float* pts; float* slab;     // slab [grid][C*5]: dw (C*4) then db (C)
   int64_t P; int C; int groups, slots;
+  const float* w; const float* b;    // Y == NULL: the layer output is recomputed from the point
 };
 __global__ __launch_bounds__(256) void lidar_l0_bwd_kernel(L0BwdArgs a) {
   __shared__ float red[256 * 4];
@@ -88,14 +85,20 @@ __global__ __launch_bounds__(256) void lidar_l0_bwd_kernel(L0BwdArgs a) {
   for (int t = 0; t < 5; ++t) acc[t] = kd_zero4();
   if (active) {
     const float4 al = kd_ld4(a.al + c0), be = kd_ld4(a.be + c0), ga = kd_ld4(a.ga + c0);
+    float4 wr[4], bias = kd_zero4();
+    if (!a.Y) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wr[j] = kd_ld4(a.w + (c0 + j) * 4);
+      if (a.b) bias = kd_ld4(a.b + c0);
+    }
     for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < a.P; p += (int64_t)gridDim.x * a.slots) {
-      const float4 d = kd_ld4(a.D + p * a.C + c0), y = kd_ld4(a.Y + p * a.C + c0);
+      const float4 pt = kd_ld4(a.pts + p * 4);
+      const float4 d = kd_ld4(a.D + p * a.C + c0), y = a.Y ? kd_ld4(a.Y + p * a.C + c0) : kd_l0_raw4(pt, wr, bias);
       float4 g;
       g.x = kd_bwd_operand(d.x, y.x, al.x, be.x, ga.x, 0.f, 0.f, KD_ACT_NONE);
       g.y = kd_bwd_operand(d.y, y.y, al.y, be.y, ga.y, 0.f, 0.f, KD_ACT_NONE);
       g.z = kd_bwd_operand(d.z, y.z, al.z, be.z, ga.z, 0.f, 0.f, KD_ACT_NONE);
       g.w = kd_bwd_operand(d.w, y.w, al.w, be.w, ga.w, 0.f, 0.f, KD_ACT_NONE);
-      const float4 pt = kd_ld4(a.pts + p * 4);
       const float pv[4] = {pt.x, pt.y, pt.z, pt.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -227,7 +230,7 @@ extern "C" {
 
 int kd_lidar_l0_fwd(const float* pts, const float* w, const float* b, float* y, float* partial, int64_t P, int C,
                     const int* p_dev, void* stream) {
-  KD_REQUIRE(pts && w && y && P > 0 && C % 4 == 0 && C <= 1024, KD_ERR_ARG, "kd_lidar_l0_fwd: bad args");
+  KD_REQUIRE(pts && w && (y || partial) && P > 0 && C % 4 == 0 && C <= 1024, KD_ERR_ARG, "kd_lidar_l0_fwd: bad args");
   const KdCgLayout l = kd_cg_layout(P, C);
   L0Args a{pts, w, b, y, partial, P, C, l.groups, l.slots, p_dev};
   hipLaunchKernelGGL(lidar_l0_fwd_kernel, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -236,13 +239,14 @@ int kd_lidar_l0_fwd(const float* pts, const float* w, const float* b, float* y, 
 
 size_t kd_lidar_l0_bwd_ws_bytes(int64_t P, int C) { return (size_t)kd_cg_layout(P, C).grid * C * 5 * sizeof(float); }
 
-// dwb: [C*4] weight gradient followed by [C] bias gradient.
-int kd_lidar_l0_bwd(const float* D, const float* Y, const float* al, const float* be, const float* ga,
-                    const float* pts, float* dwb, int64_t P, int C, void* ws, size_t ws_bytes, void* stream) {
-  KD_REQUIRE(D && Y && al && be && ga && pts && dwb && ws && P > 0 && C % 4 == 0, KD_ERR_ARG, "kd_lidar_l0_bwd: bad args");
+// dwb: [C*4] weight gradient followed by [C] bias gradient.  Y == NULL: the layer output is recomputed from (w, b).
+int kd_lidar_l0_bwd(const float* D, const float* Y, const float* w, const float* b, const float* al, const float* be,
+                    const float* ga, const float* pts, float* dwb, int64_t P, int C, void* ws, size_t ws_bytes,
+                    void* stream) {
+  KD_REQUIRE(D && (Y || w) && al && be && ga && pts && dwb && ws && P > 0 && C % 4 == 0, KD_ERR_ARG, "kd_lidar_l0_bwd: bad args");
   const KdCgLayout l = kd_cg_layout(P, C);
   KD_REQUIRE(ws_bytes >= (size_t)l.grid * C * 5 * sizeof(float), KD_ERR_WORKSPACE, "kd_lidar_l0_bwd: workspace too small");
-  L0BwdArgs a{D, Y, al, be, ga, pts, (float*)ws, P, C, l.groups, l.slots};
+  L0BwdArgs a{D, Y, al, be, ga, pts, (float*)ws, P, C, l.groups, l.slots, w, b};
   hipLaunchKernelGGL(lidar_l0_bwd_kernel, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   int rc = kd_check_launch("kd_lidar_l0_bwd");
   if (rc) return rc;

@@ -54,19 +54,21 @@ class BNC:
 
 class Operand:
     """A possibly-deferred NHWC activation: value = act(raw*sc+sh), or raw itself when bnc is None.
-    raw is a [M, C] view (row stride = ld); geom = (B, H, W) with M = B*H*W."""
-    __slots__ = ("raw", "bnc", "act", "geom")
+    raw is a [M, C] view (row stride = ld); geom = (B, H, W) with M = B*H*W.
+    A VIRTUAL operand (raw is None, virt = (points [M,4], w0 [C,4,1], b0 [C])) is the LiDAR layer-0 output, which is
+    never written: consumers recompute it from the 16-byte point (kd_lidar_l1_*)."""
+    __slots__ = ("raw", "bnc", "act", "geom", "virt")
 
-    def __init__(self, raw: torch.Tensor, geom, bnc: Optional[BNC] = None, act: int = ACT_NONE):
-        self.raw, self.bnc, self.act, self.geom = raw, bnc, act, geom
+    def __init__(self, raw: Optional[torch.Tensor], geom, bnc: Optional[BNC] = None, act: int = ACT_NONE, virt=None):
+        self.raw, self.bnc, self.act, self.geom, self.virt = raw, bnc, act, geom, virt
 
     @property
     def M(self):
-        return self.raw.shape[0]
+        return self.raw.shape[0] if self.raw is not None else self.virt[0].shape[0]
 
     @property
     def C(self):
-        return self.raw.shape[1]
+        return self.raw.shape[1] if self.raw is not None else self.virt[1].shape[0]
 
     @property
     def sc(self):
@@ -158,6 +160,36 @@ def pw_gemm(A, W, C_out, *, M, K, N, A2=None, pro=0, pro_act=0, p=(None,) * 5, b
     # algorithmic bytes: every operand tensor of the launch read or written exactly once
     _prof_end(e0, "pw_gemm", 2.0 * M * N * K,
               4.0 * (M * K * (2 if pro == 2 else 1) + M * N * (1 + (epi == 2) + (addend is not None)) + N * K))
+
+
+def l1_fwd(op: Operand, W, C_out, *, bias, epi, partial, m_dev=None):
+    """LiDAR layer 1 forward over a virtual layer-0 operand (pts -> layer 0 -> BN+act recomputed on load)."""
+    pts, w0, b0 = op.virt
+    M, K, N = pts.shape[0], w0.shape[0], W.shape[0]
+    e0 = _prof_begin()
+    lib.call("kd_lidar_l1_fwd", P(pts), P(w0), P(b0), P(op.sc), P(op.sh), op.act, P(W), P(bias), P(C_out), ld(C_out), epi,
+             P(partial), M, K, N, P(m_dev), stream())
+    _prof_end(e0, "pw_gemm", 2.0 * M * N * K, 4.0 * (M * 4 + M * N + N * K))
+
+
+def l1_dgrad(t, y, Wt, gin, *, op: Operand, al, be, ga, msc, msh, mact, partial):
+    pts, w0, b0 = op.virt
+    M, N1, K0 = pts.shape[0], y.shape[1], w0.shape[0]
+    e0 = _prof_begin()
+    lib.call("kd_lidar_l1_dgrad", P(t), ld(t), P(y), ld(y), P(al), P(be), P(ga), P(msc), P(msh), mact, P(Wt), P(gin), ld(gin),
+             P(pts), P(w0), P(b0), P(op.sc), P(op.sh), P(op.bnc.mean), P(op.bnc.invstd), op.act, P(partial), M, N1, K0, stream())
+    _prof_end(e0, "pw_gemm", 2.0 * M * N1 * K0, 4.0 * (2 * M * N1 + M * K0 + M * 4 + N1 * K0))
+
+
+def l1_wgrad(t, y, dW, *, op: Operand, al, be, ga, msc, msh, mact):
+    pts, w0, b0 = op.virt
+    M, N, K = pts.shape[0], y.shape[1], w0.shape[0]
+    nbytes = lib.kd_pwconv_wgrad_ws_bytes(M, N, K)
+    ws = workspace(nbytes, t.device)
+    e0 = _prof_begin()
+    lib.call("kd_lidar_l1_wgrad", P(t), ld(t), P(y), ld(y), mact, P(al), P(be), P(ga), P(msc), P(msh), P(pts), P(w0), P(b0),
+             P(op.sc), P(op.sh), op.act, P(dW), M, N, K, P(ws), nbytes, stream())
+    _prof_end(e0, "pw_wgrad", 2.0 * M * N * K, 4.0 * (2 * M * N + M * 4 + N * K))
 
 
 def pw_wgrad(D, A, dW, *, M, N, K, X=None, d_mode=0, d_act=0, al=None, be=None, ga=None, msc=None, msh=None,

@@ -61,7 +61,7 @@ def _coeffs(spec: UnitSpec, partial, rows, C, count, training, bnc=None, device=
 
 
 def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] = None, bnc: Optional[BNC] = None,
-                 m_dev: Optional[torch.Tensor] = None):
+                 m_dev: Optional[torch.Tensor] = None, virtual: bool = False):
     """inp: Operand (or, for 'stem', the NCHW image tensor; for 'l0', the [P,4] points).
     Returns (output Operand, record for backward)."""
     rec = _Rec()
@@ -75,15 +75,18 @@ def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] 
         M = inp.M
         if inp.C != K:
             raise KDError(f"pointwise conv expects {K} input channels, got {inp.C}")
-        dev = inp.raw.device
+        dev = w.device
         if y is None:
             y = torch.empty(M, N, device=dev, dtype=torch.float32)
         partial, rows = None, 0
         if training:
             rows = lib.kd_pwconv_stat_rows(M)
             partial = torch.empty(rows * 2 * N, device=dev, dtype=torch.float32)
-        ops.pw_gemm(inp.raw, w, y, M=M, K=K, N=N, pro=1 if inp.bnc is not None else 0, pro_act=inp.act,
-                    p=(inp.sc, inp.sh, None, None, None), bias=b, epi=1 if training else 0, partial=partial, m_dev=m_dev)
+        if inp.virt is not None:
+            ops.l1_fwd(inp, w, y, bias=b, epi=1 if training else 0, partial=partial, m_dev=m_dev)
+        else:
+            ops.pw_gemm(inp.raw, w, y, M=M, K=K, N=N, pro=1 if inp.bnc is not None else 0, pro_act=inp.act,
+                        p=(inp.sc, inp.sh, None, None, None), bias=b, epi=1 if training else 0, partial=partial, m_dev=m_dev)
         rec.out_geom = inp.geom
         rec.bnc = _coeffs(spec, partial, rows, N, M, training, bnc, dev)
     elif kind == "dw":
@@ -123,14 +126,20 @@ def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] 
         pts = inp                                    # [P, 4] contiguous
         Pn, C = pts.shape[0], w.shape[0]
         dev = pts.device
-        y = torch.empty(Pn, C, device=dev, dtype=torch.float32)
+        # virtual: the [P, C] output is never written -- only the BatchNorm statistics pass runs (training), and the
+        # next layer recomputes layer 0 from the points on load
+        y = None if virtual else torch.empty(Pn, C, device=dev, dtype=torch.float32)
         partial, rows = None, 0
         if training:
             rows = lib.kd_rowwise_stat_rows(Pn, C)
             partial = torch.empty(rows * 2 * C, device=dev, dtype=torch.float32)
-        lib.call("kd_lidar_l0_fwd", P(pts), P(w), P(b), P(y), P(partial), Pn, C, P(m_dev), stream())
+        if training or not virtual:
+            lib.call("kd_lidar_l0_fwd", P(pts), P(w), P(b), P(y), P(partial), Pn, C, P(m_dev), stream())
         rec.out_geom = (Pn, 1, 1)
         rec.bnc = _coeffs(spec, partial, rows, C, Pn, training, bnc, dev)
+        if virtual:
+            rec.y = None
+            return Operand(None, rec.out_geom, rec.bnc, spec.act, virt=(pts, w, b)), rec
     elif kind == "ct":
         B, H, W = inp.geom
         Cin, Cout = w.shape[0], w.shape[1]
@@ -162,7 +171,7 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
     g_in is ("G", ...) if the input was deferred, a plain [M, C] tensor if it was materialised, or None."""
     spec = rec.spec
     y, bnc = rec.y, rec.bnc
-    M, C = y.shape
+    M, C = y.shape if y is not None else (rec.inp.shape[0], rec.w.shape[0])      # y None: virtual LiDAR layer 0
     out_op = Operand(y, rec.out_geom, bnc, spec.act)
     pstride = None
     if g[0] == "D":
@@ -184,18 +193,29 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
                                                     want_dbias=want_dbias, pstride=pstride, dgamma=g_buf, dbeta=b_buf,
                                                     dbias=cb_buf)
     al, be, ga = abg[0], abg[1], abg[2]
-    dev = y.device
+    dev = rec.w.device
     kind = spec.kind
     g_in = None
     if kind == "pw":
         inp = rec.inp
         N, K = C, inp.C
         dW, w_dir = gradsink.out_for(rec.w)
-        ops.pw_wgrad(t, inp.raw, dW, M=M, N=N, K=K, X=y, d_mode=2, d_act=mact, al=al, be=be, ga=ga, msc=msc, msh=msh,
-                     a_mode=1 if inp.bnc is not None else 0, a_act=inp.act, asc=inp.sc, ash=inp.sh)
+        if inp.virt is not None:
+            ops.l1_wgrad(t, y, dW, op=inp, al=al, be=be, ga=ga, msc=msc, msh=msh, mact=mact)
+        else:
+            ops.pw_wgrad(t, inp.raw, dW, M=M, N=N, K=K, X=y, d_mode=2, d_act=mact, al=al, be=be, ga=ga, msc=msc, msh=msh,
+                         a_mode=1 if inp.bnc is not None else 0, a_act=inp.act, asc=inp.sc, ash=inp.sh)
         if need_input_grad:
             Wt = ops.transpose(rec.w.view(N, K))
-            if inp.bnc is not None:
+            if inp.virt is not None:
+                if addend is not None:
+                    raise KDError("addend on a virtual LiDAR layer-0 input is not supported")
+                gin = torch.empty(M, K, device=dev, dtype=torch.float32)
+                rows_in = lib.kd_pwconv_stat_rows(M)
+                part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
+                ops.l1_dgrad(t, y, Wt, gin, op=inp, al=al, be=be, ga=ga, msc=msc, msh=msh, mact=mact, partial=part_in)
+                g_in = ("G", gin, part_in, rows_in)
+            elif inp.bnc is not None:
                 gin = torch.empty(M, K, device=dev, dtype=torch.float32)
                 rows_in = lib.kd_pwconv_stat_rows(M)
                 part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
@@ -254,7 +274,8 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
         nbytes = lib.kd_lidar_l0_bwd_ws_bytes(M, C)
         ws = ops.workspace(nbytes, dev)
         dwb = torch.empty(C * 5, device=dev, dtype=torch.float32)
-        lib.call("kd_lidar_l0_bwd", P(t), P(y), P(al), P(be), P(ga), P(pts), P(dwb), M, C, P(ws), nbytes, stream())
+        lib.call("kd_lidar_l0_bwd", P(t), P(y), P(rec.w), P(rec.b), P(al), P(be), P(ga), P(pts), P(dwb), M, C, P(ws), nbytes,
+                 stream())
         grads = [gradsink.deliver(rec.w, dwb[: C * 4]), gradsink.deliver(rec.b, dwb[C * 4:])]
     elif kind == "ct":
         inp = rec.inp
@@ -705,14 +726,14 @@ class LidarFn(torch.autograd.Function):
             grid = torch.empty(B * H * W, C, device=dev, dtype=torch.float32)
             cur = cpts
             for u in units:
-                cur, _ = unit_forward(u, cur, False, m_dev=counter)
+                cur, _ = unit_forward(u, cur, False, m_dev=counter, virtual=(u.kind == "l0"))
             lib.call("kd_lidar_scatter_max_idx_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(ccell), P(grid), B * N, C,
                      B * H * W, P(counter), stream())
             return ops.nchw_from_matrix(grid, (B, H, W))
         cur = pts
         recs = []
         for u in units:
-            cur, rec = unit_forward(u, cur, training)
+            cur, rec = unit_forward(u, cur, training, virtual=(u.kind == "l0"))
             recs.append(rec)
         H, W = grid_hw
         C = cur.C
