@@ -128,6 +128,11 @@ size_t kd_lidar_l0_bwd_ws_bytes(int64_t P, int C);
 /* Y == NULL: the layer output is recomputed from (w, b) and the point (it was never written, see kd_lidar_l1_*) */
 int kd_lidar_l0_bwd(const float* D, const float* Y, const float* w, const float* b, const float* al, const float* be, const float* ga,
                     const float* pts, float* dwb, int64_t P, int C, void* ws, size_t ws_bytes, void* stream);
+/* eval mode: last point-MLP layer + BatchNorm + ReLU + BEV scatter-max in one kernel (zeroes `grid` first); rows are the
+ * compacted in-range points, cell_idx[p] their flat (frame, cell) grid row; the layer output is never written */
+int kd_lidar_l2_fwd_scatter(const float* A, int64_t lda, const float* sc1, const float* sh1, int act1, const float* W2,
+                            const float* bias2, const float* sc2, const float* sh2, int act2, const int* cell_idx,
+                            float* grid, int64_t ncells, int64_t M, int K, int N, const int* m_dev, void* stream);
 int kd_lidar_scatter_max_fwd(const float* pts, const float* y, const float* sc, const float* sh, int act,
                              float* grid, int B, int64_t N, int C, int H, int W, float x0, float x1, float y0,
                              float y1, void* stream);

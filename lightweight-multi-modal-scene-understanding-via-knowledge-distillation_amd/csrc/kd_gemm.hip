@@ -307,6 +307,66 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
   }
   KD_PH(4);                            // MFMA phases (incl. issuing the prefetch)
 
+  // ---- EPI4: eval BatchNorm + ReLU + BEV scatter-max straight from the accumulator tile -----------------------
+  // (frozen teacher / validation: the [points, C] output of the last point-MLP layer is never written).  X = int
+  // cell index per row (flat (frame, cell) row of the grid, < 0: skip), C = grid [cells][ldc], zero-initialised by the
+  // caller.  Values are >= 0 after ReLU, so max == unsigned max of the bit pattern (order-independent, deterministic).
+  // Lanes map to CONSECUTIVE channels (4-byte accesses) so one wave's atomics fall in few cache lines, and all
+  // current-maximum reads of a half are issued before its first atomic (in-order vmcnt: see the note below).
+  if constexpr (EPI == 4) {
+    constexpr int TLD4 = BNt + 4, NJ = BNt / 32, NP = WM * 4;         // 8 rows per pass, NP passes per half
+    float* T4 = smem;
+    const int l32 = tid & 31, r8 = tid >> 5;
+    float s4[NJ], h4[NJ], b4[NJ];
+    bool ok4[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = n0 + l32 + 32 * j;
+      ok4[j] = c < g.N;
+      const int cc = ok4[j] ? c : g.N - 1;
+      s4[j] = g.esc[cc]; h4[j] = g.esh[cc];
+      b4[j] = g.bias ? g.bias[cc] : 0.f;
+    }
+    const int* cellidx = reinterpret_cast<const int*>(g.X);
+    unsigned* grid = reinterpret_cast<unsigned*>(g.C);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      kd_lds_barrier();
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          T4[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TLD4 + wc * 64 + ni * 32 + (lane & 31)] = acc[h][ni][r];
+      kd_lds_barrier();
+      int cell[NP];
+      unsigned cur[NP][NJ];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int rr = r8 + 8 * i;
+        int64_t row = m0 + (rr >> 5) * 64 + h * 32 + (rr & 31);
+        const bool rok = row < g.M;
+        row = rok ? row : (int64_t)g.M - 1;
+        const int c = cellidx[row];
+        cell[i] = rok ? c : -1;
+        const unsigned* src = grid + (int64_t)(c < 0 ? 0 : c) * g.ldc + n0 + l32;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cur[i][j] = src[ok4[j] ? 32 * j : 0];
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int rr = r8 + 8 * i;
+        unsigned* dst = grid + (int64_t)(cell[i] < 0 ? 0 : cell[i]) * g.ldc + n0 + l32;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float v = kd_act(kd_affine(T4[rr * TLD4 + l32 + 32 * j] + b4[j], s4[j], h4[j]), g.epi_act);
+          const unsigned u = __float_as_uint(v);
+          if (cell[i] >= 0 && ok4[j] && v > 0.f && u > cur[i][j]) atomicMax(dst + 32 * j, u);
+        }
+      }
+    }
+    return;
+  }
+
   // ---- epilogue ---------------------------------------------------------------------------------
   // The accumulator tile goes through LDS in two halves (the mi = 0 / 1 row groups of every wave) so
   // that C stores and the X / addend loads are whole rows (float4 per lane, BNt*4 contiguous bytes)
@@ -731,6 +791,7 @@ int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {
   KD_GEMM_CASE(1, 0) KD_GEMM_CASE(1, 1) KD_GEMM_CASE(1, 2)
   KD_GEMM_CASE(2, 0) KD_GEMM_CASE(2, 1) KD_GEMM_CASE(2, 2)
   KD_GEMM_CASE(3, 0) KD_GEMM_CASE(3, 1) KD_GEMM_CASE(2, 3)      // LiDAR layer 0 recomputed from the points
+  KD_GEMM_CASE(1, 4)                                              // last point-MLP layer + BEV scatter-max (eval)
 #undef KD_GEMM_CASE
   return kd_check_launch("kd_pwconv_gemm");
 }
@@ -867,6 +928,25 @@ int kd_lidar_l1_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, 
   if (!msc) { msc = al; msh = al; }
   WgradArgs g{D, ldd, X, ldx, al, be, ga, msc, msh, 2, d_act, pts, 4, sc0, sh0, 2, act0, (float*)ws, (int)M, N, K, 0, w0, b0};
   return wgrad_launch(g, ws_bytes, dW, (hipStream_t)stream);
+}
+
+// Last point-MLP layer in eval mode fused with the BEV scatter-max: grid[cell_idx[p], :] = max(grid, act2(bn2(
+// act1(bn1(A[p])) . W2^T + bias2))) for rows p < *m_dev; the [points, N] layer output is never written.
+int kd_lidar_l2_fwd_scatter(const float* A, int64_t lda, const float* sc1, const float* sh1, int act1, const float* W2,
+                            const float* bias2, const float* sc2, const float* sh2, int act2, const int* cell_idx,
+                            float* grid, int64_t ncells, int64_t M, int K, int N, const int* m_dev, void* stream) {
+  KD_REQUIRE(A && sc1 && sh1 && W2 && sc2 && sh2 && cell_idx && grid && ncells > 0 && M > 0 && K >= 4 && N > 0, KD_ERR_ARG,
+             "kd_lidar_l2_fwd_scatter: bad args");
+  KD_REQUIRE(M < (int64_t)1 << 31 && K % 4 == 0 && lda % 4 == 0 && N % 4 == 0, KD_ERR_SHAPE, "kd_lidar_l2_fwd_scatter: K, N, lda must be multiples of 4");
+  KD_REQUIRE(act2 == KD_ACT_RELU || act2 == KD_ACT_RELU6, KD_ERR_ARG, "kd_lidar_l2_fwd_scatter: needs a non-negative activation");
+  KD_REQUIRE(kd_aligned16(A) && kd_aligned16(W2) && kd_aligned16(sc1) && kd_aligned16(sh1), KD_ERR_ALIGN, "kd_lidar_l2_fwd_scatter: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(grid, 0, (size_t)ncells * N * sizeof(float), st);
+  KD_REQUIRE(e == hipSuccess, (int)e, "kd_lidar_l2_fwd_scatter: memset failed: %s", hipGetErrorString(e));
+  GemmArgs g{A, lda, nullptr, 0, sc1, sh1, nullptr, nullptr, nullptr, 1, act1, W2, bias2, grid, N, nullptr, 0,
+             reinterpret_cast<const float*>(cell_idx), 0, sc2, sh2, nullptr, nullptr, act2, nullptr, (int)M, K, N, m_dev,
+             nullptr, nullptr};
+  return gemm_launch(g, 1, 4, st);
 }
 
 // out[c][r] = in[r][c] -- used once per step per weight to get W^T for the dgrad GEMM.

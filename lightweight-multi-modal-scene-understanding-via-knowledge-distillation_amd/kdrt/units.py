@@ -722,13 +722,22 @@ class LidarFn(torch.autograd.Function):
                      float(rng[2]), float(rng[3]), stream())
             # the row count stays on the device: the kernels read it themselves (no host sync, the CPU keeps
             # running a whole step ahead of the GPU)
-            C = units[-1].conv.weight.shape[0]
+            last = units[-1]
+            C = last.conv.weight.shape[0]
             grid = torch.empty(B * H * W, C, device=dev, dtype=torch.float32)
             cur = cpts
-            for u in units:
+            for u in units[:-1]:
                 cur, _ = unit_forward(u, cur, False, m_dev=counter, virtual=(u.kind == "l0"))
-            lib.call("kd_lidar_scatter_max_idx_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(ccell), P(grid), B * N, C,
-                     B * H * W, P(counter), stream())
+            if last.kind == "pw" and cur.virt is None and cur.bnc is not None:
+                # last layer + BN + ReLU + scatter-max in one kernel: its [points, C] output is never written
+                bnc = _coeffs(last, None, 0, C, 0, False, None, dev)
+                lib.call("kd_lidar_l2_fwd_scatter", P(cur.raw), ld(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(last.conv.weight),
+                         P(last.conv.bias), P(bnc.scale), P(bnc.shift), last.act, P(ccell), P(grid), B * H * W, B * N,
+                         cur.C, C, P(counter), stream())
+            else:
+                cur, _ = unit_forward(last, cur, False, m_dev=counter)
+                lib.call("kd_lidar_scatter_max_idx_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(ccell), P(grid), B * N, C,
+                         B * H * W, P(counter), stream())
             return ops.nchw_from_matrix(grid, (B, H, W))
         cur = pts
         recs = []
