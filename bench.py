@@ -194,9 +194,11 @@ def main():
     if rank == 0 and not args.no_roofline:
         recs, ops.PROFILE = ops.PROFILE, None
         agg = {}
-        for kind, flops, nbytes, e0, e1 in recs:
+        torch.cuda.synchronize()
+        for rec in recs:
+            kind, flops, nbytes, secs = ops.prof_scaled(rec)      # compacted-point launches: actual row count
             a = agg.setdefault(kind, [0.0, 0.0, 0.0, 0])
-            a[0] += flops; a[1] += nbytes; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += 1
+            a[0] += flops; a[1] += nbytes; a[2] += secs; a[3] += 1
         g = agg.get("pw_gemm", [0, 0, 1e-9, 0])
         w = agg.get("pw_wgrad", [0, 0, 1e-9, 0])
         # The family is HBM-bound since its products moved to the bf16 matrix pipe (bf16x6 split arithmetic): the

@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
     }
     const int* cellidx = reinterpret_cast<const int*>(g.X);
     unsigned* grid = reinterpret_cast<unsigned*>(g.C);
+    const int cb4 = n0 + l32 < g.N ? n0 + l32 : 0;       // first column of this lane (clamped: partial column tiles)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       kd_lds_barrier();
@@ -348,14 +349,14 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
         row = rok ? row : (int64_t)g.M - 1;
         const int c = cellidx[row];
         cell[i] = rok ? c : -1;
-        const unsigned* src = grid + (int64_t)(c < 0 ? 0 : c) * g.ldc + n0 + l32;
+        const unsigned* src = grid + (int64_t)(c < 0 ? 0 : c) * g.ldc + cb4;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) cur[i][j] = src[ok4[j] ? 32 * j : 0];
       }
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const int rr = r8 + 8 * i;
-        unsigned* dst = grid + (int64_t)(cell[i] < 0 ? 0 : cell[i]) * g.ldc + n0 + l32;
+        unsigned* dst = grid + (int64_t)(cell[i] < 0 ? 0 : cell[i]) * g.ldc + cb4;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const float v = kd_act(kd_affine(T4[rr * TLD4 + l32 + 32 * j] + b4[j], s4[j], h4[j]), g.epi_act);
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
   // The accumulator tile goes through LDS in two halves (the mi = 0 / 1 row groups of every wave) so
   // that C stores and the X / addend loads are whole rows (float4 per lane, BNt*4 contiguous bytes)
   // instead of 4-byte column-strided accesses.
+  constexpr bool EPI_BWD = EPI == 2 || EPI == 3;        // dgrad epilogues: multiply by act'(X), BN-backward sums
   constexpr int TLD = BNt + 4;
   constexpr int CPT = BNt / 4, RG = 256 / CPT;        // column groups, row groups; 8 iterations cover WM*32 rows
   static_assert(WM * 32 * TLD <= SMEM_FLOATS, "epilogue staging must fit the operand LDS");
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
     const float4 bv = kd_ld4(bp + (g.bias ? colc : 0));
     const bool hb = g.bias != nullptr;
     bias4 = make_float4(hb ? bv.x : 0.f, hb ? bv.y : 0.f, hb ? bv.z : 0.f, hb ? bv.w : 0.f);
-    if (EPI >= 2) { esc = kd_ld4(g.esc + colc); esh = kd_ld4(g.esh + colc); emean = kd_ld4(g.emean + colc); einv = kd_ld4(g.einv + colc); }
+    if (EPI_BWD) { esc = kd_ld4(g.esc + colc); esh = kd_ld4(g.esh + colc); emean = kd_ld4(g.emean + colc); einv = kd_ld4(g.einv + colc); }
   }
   float4 ew[EPI == 3 ? 4 : 1], eb = kd_zero4();      // EPI3: X is layer 0 of the point, recomputed for the thread's 4 columns
   if (EPI == 3) {
@@ -414,8 +416,8 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
     KD_PHE(2);
     // All global LOADS of this half are issued before its first store (clamped addresses, no branches), so no
     // wait on a load ever has an older store in front of it in the in-order vmcnt queue.
-    float4 xr[EPI >= 2 ? NI : 1];
-    if (EPI >= 2) {
+    float4 xr[EPI_BWD ? NI : 1];
+    if (EPI_BWD) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int rr = rg + RG * i;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
       const bool ok = cok && row < g.M;
       float4 v = kd_ld4(T + rr * TLD + c4e * 4);
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-      if (EPI >= 2) {
+      if (EPI_BWD) {
         float4 x = xr[i];
         if constexpr (EPI == 3) x = kd_l0_raw4(xr[i], ew, eb);
         v.x *= kd_act_mask(kd_affine(x.x, esc.x, esh.x), g.epi_act);

@@ -143,11 +143,20 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, kind, flops, nbytes):
+def _prof_end(e0, kind, flops, nbytes, m_dev=None, M=None):
+    """flops / nbytes are for M rows; with a device-side row count (compacted LiDAR points) the reader scales them by
+    min(m_dev, M) / M after the run (prof_scaled) -- no host sync here."""
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        PROFILE.append((kind, flops, nbytes, e0, e1))
+        PROFILE.append((kind, flops, nbytes, e0, e1, m_dev, M))
+
+
+def prof_scaled(rec):
+    """(kind, flops, bytes, seconds) of one PROFILE record, row-count corrected (call after a device synchronise)."""
+    kind, flops, nbytes, e0, e1, m_dev, M = rec
+    f = 1.0 if m_dev is None else min(int(m_dev.item()), M) / float(M)
+    return kind, flops * f, nbytes * f, e0.elapsed_time(e1) * 1e-3
 
 
 def pw_gemm(A, W, C_out, *, M, K, N, A2=None, pro=0, pro_act=0, p=(None,) * 5, bias=None, addend=None, epi=0,
@@ -159,7 +168,7 @@ def pw_gemm(A, W, C_out, *, M, K, N, A2=None, pro=0, pro_act=0, p=(None,) * 5, b
              P(esc), P(esh), P(emean), P(einv), epi_act, P(partial), M, K, N, P(m_dev), stream())
     # algorithmic bytes: every operand tensor of the launch read or written exactly once
     _prof_end(e0, "pw_gemm", 2.0 * M * N * K,
-              4.0 * (M * K * (2 if pro == 2 else 1) + M * N * (1 + (epi == 2) + (addend is not None)) + N * K))
+              4.0 * (M * K * (2 if pro == 2 else 1) + M * N * (1 + (epi == 2) + (addend is not None)) + N * K), m_dev, M)
 
 
 def l1_fwd(op: Operand, W, C_out, *, bias, epi, partial, m_dev=None):
@@ -169,7 +178,16 @@ def l1_fwd(op: Operand, W, C_out, *, bias, epi, partial, m_dev=None):
     e0 = _prof_begin()
     lib.call("kd_lidar_l1_fwd", P(pts), P(w0), P(b0), P(op.sc), P(op.sh), op.act, P(W), P(bias), P(C_out), ld(C_out), epi,
              P(partial), M, K, N, P(m_dev), stream())
-    _prof_end(e0, "pw_gemm", 2.0 * M * N * K, 4.0 * (M * 4 + M * N + N * K))
+    _prof_end(e0, "pw_gemm", 2.0 * M * N * K, 4.0 * (M * 4 + M * N + N * K), m_dev, M)
+
+
+def l2_fwd_scatter(op: Operand, W, bias, bnc2: BNC, act2, cell_idx, grid, ncells, m_dev):
+    """Eval: last point-MLP layer + BN + ReLU + BEV scatter-max in one kernel (the layer output is never written)."""
+    M, K, N = op.M, op.C, W.shape[0]
+    e0 = _prof_begin()
+    lib.call("kd_lidar_l2_fwd_scatter", P(op.raw), ld(op.raw), P(op.sc), P(op.sh), op.act, P(W), P(bias), P(bnc2.scale),
+             P(bnc2.shift), act2, P(cell_idx), P(grid), ncells, M, K, N, P(m_dev), stream())
+    _prof_end(e0, "pw_gemm", 2.0 * M * N * K, 4.0 * (M * K + M * 1 + N * K), m_dev, M)     # reads A + cell index; no output tensor
 
 
 def l1_dgrad(t, y, Wt, gin, *, op: Operand, al, be, ga, msc, msh, mact, partial):

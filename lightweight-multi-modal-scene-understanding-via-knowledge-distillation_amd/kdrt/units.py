@@ -731,9 +731,7 @@ class LidarFn(torch.autograd.Function):
             if last.kind == "pw" and cur.virt is None and cur.bnc is not None:
                 # last layer + BN + ReLU + scatter-max in one kernel: its [points, C] output is never written
                 bnc = _coeffs(last, None, 0, C, 0, False, None, dev)
-                lib.call("kd_lidar_l2_fwd_scatter", P(cur.raw), ld(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(last.conv.weight),
-                         P(last.conv.bias), P(bnc.scale), P(bnc.shift), last.act, P(ccell), P(grid), B * H * W, B * N,
-                         cur.C, C, P(counter), stream())
+                ops.l2_fwd_scatter(cur, last.conv.weight, last.conv.bias, bnc, last.act, ccell, grid, B * H * W, counter)
             else:
                 cur, _ = unit_forward(last, cur, False, m_dev=counter)
                 lib.call("kd_lidar_scatter_max_idx_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(ccell), P(grid), B * N, C,
