@@ -287,9 +287,34 @@ __global__ __launch_bounds__(256) void dw_bwd_data_sw_kernel(DwBwdArgs a) {
   if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
 }
 
-// stride-2 data gradient, branch-free: input pixel (hi, wi) receives from at most 2 x 2 output pixels:
-//   row candidates  a: kh = (hi+1)&1, ho = (hi+1-kh)/2      b (only if kh_a == 0): kh = 2, ho = ho_a - 1
-// (same along w).  All four dyeff values are loaded from clamped addresses and masked by selects.
+// stride-2 data gradient.  Work item = a column of 2x2 input QUADS (b, 8 quad rows, quad column q): the quad with
+// top-left input pixel (2a, 2q) receives from exactly the four outputs (a, q), (a, q+1), (a+1, q), (a+1, q+1):
+//   gx(2a  , 2q  ) = d00 w11                      gx(2a  , 2q+1) = d01 w10 + d00 w12
+//   gx(2a+1, 2q  ) = d10 w01 + d00 w21            gx(2a+1, 2q+1) = d11 w00 + d10 w02 + d01 w20 + d00 w22
+// so sliding down the quad rows costs TWO new dy values per four input pixels (the per-pixel form loaded and
+// BN-transformed four candidates per pixel: 8x the loads and arithmetic of this one).  Loads are branch-free
+// (clamped addresses, zero selects).
+struct DwRaw { float4 d, y; };
+__device__ __forceinline__ DwRaw dw_dy_raw(const DwBwdArgs& a, int b, int ho, int wo, int c0) {   // clamped, no branches
+  const int hoc = ho < a.Ho ? ho : a.Ho - 1, woc = wo < a.Wo ? wo : a.Wo - 1;
+  const int64_t q = (((int64_t)b * a.Ho + hoc) * a.Wo + woc) * a.C + c0;
+  DwRaw r;
+  r.d = kd_ld4(a.D + q);
+  r.y = kd_ld4((a.al ? a.Y : a.D) + q);
+  return r;
+}
+__device__ __forceinline__ float4 dw_dy_finish(const DwBwdArgs& a, DwRaw r, bool ok, float4 al, float4 be, float4 ga, float4 dsc,
+                                               float4 dsh) {
+  float4 v = r.d;
+  if (a.al) {
+    v.x = kd_bwd_operand(r.d.x, r.y.x, al.x, be.x, ga.x, dsc.x, dsh.x, a.d_act);
+    v.y = kd_bwd_operand(r.d.y, r.y.y, al.y, be.y, ga.y, dsc.y, dsh.y, a.d_act);
+    v.z = kd_bwd_operand(r.d.z, r.y.z, al.z, be.z, ga.z, dsc.z, dsh.z, a.d_act);
+    v.w = kd_bwd_operand(r.d.w, r.y.w, al.w, be.w, ga.w, dsc.w, dsh.w, a.d_act);
+  }
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(DwBwdArgs a) {
   __shared__ float red[2 * 256 * 4];
   const int tid = threadIdx.x;
@@ -298,55 +323,86 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(DwBwdArgs a) {
   const int c0 = gidx * 4;
   float4 s1 = kd_zero4(), s2 = kd_zero4();
   if (active) {
-    float wreg[4][9];
+    float4 wt[9];                         // wt[t] = tap t of the thread's 4 channels
+    {
+      float wreg[4][9];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int t = 0; t < 9; ++t) wreg[j][t] = a.w[(c0 + j) * 9 + t];
+        for (int t = 0; t < 9; ++t) wreg[j][t] = a.w[(c0 + j) * 9 + t];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wt[t] = make_float4(wreg[0][t], wreg[1][t], wreg[2][t], wreg[3][t]);
+    }
     float4 al = kd_zero4(), be = kd_zero4(), ga = kd_zero4(), dsc = kd_zero4(), dsh = kd_zero4();
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4(), mean = kd_zero4(), inv = kd_zero4();
     if (a.al) { al = kd_ld4(a.al + c0); be = kd_ld4(a.be + c0); ga = kd_ld4(a.ga + c0); }
     if (a.dsc) { dsc = kd_ld4(a.dsc + c0); dsh = kd_ld4(a.dsh + c0); }
     if (a.sc) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
     if (a.mean) { mean = kd_ld4(a.mean + c0); inv = kd_ld4(a.invstd + c0); }
-    const int64_t npix = (int64_t)a.B * a.H * a.W;
-    for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < npix; p += (int64_t)gridDim.x * a.slots) {
-      const int wi = (int)(p % a.W), hi = (int)((p / a.W) % a.H), b = (int)(p / ((int64_t)a.W * a.H));
-      const int kha = (hi + 1) & 1, hoa = (hi + 1 - kha) >> 1, hob = hoa - 1;
-      const int kwa = (wi + 1) & 1, woa = (wi + 1 - kwa) >> 1, wob = woa - 1;
-      const bool ha = hoa < a.Ho, hb = kha == 0 && hob >= 0;
-      const bool wa = woa < a.Wo, wb = kwa == 0 && wob >= 0;
-      const int hoac = ha ? hoa : a.Ho - 1, hobc = hob >= 0 ? hob : 0;
-      const int woac = wa ? woa : a.Wo - 1, wobc = wob >= 0 ? wob : 0;
-      const int64_t ba = ((int64_t)b * a.Ho + hoac) * a.Wo, bb = ((int64_t)b * a.Ho + hobc) * a.Wo;
-      const float4 daa = dw_dyeff(a, ba + woac, c0, al, be, ga, dsc, dsh), dab = dw_dyeff(a, ba + wobc, c0, al, be, ga, dsc, dsh);
-      const float4 dba = dw_dyeff(a, bb + woac, c0, al, be, ga, dsc, dsh), dbb = dw_dyeff(a, bb + wobc, c0, al, be, ga, dsc, dsh);
-      const float faa = (ha && wa) ? 1.f : 0.f, fab = (ha && wb) ? 1.f : 0.f, fba = (hb && wa) ? 1.f : 0.f, fbb = (hb && wb) ? 1.f : 0.f;
-      float4 acc;
-      float* accp = reinterpret_cast<float*>(&acc);
-      const float* paa = reinterpret_cast<const float*>(&daa); const float* pab = reinterpret_cast<const float*>(&dab);
-      const float* pba = reinterpret_cast<const float*>(&dba); const float* pbb = reinterpret_cast<const float*>(&dbb);
+    const bool masked = a.sc != nullptr;
+    const int QH = (a.H + 1) / 2, QW = (a.W + 1) / 2;
+    constexpr int QSEG = DW_SEG / 2;
+    const int nseg = (QH + QSEG - 1) / QSEG;
+    const int64_t items = (int64_t)a.B * nseg * QW;
+    // raw x of the quad's four pixels (clamped addresses; pixels outside an odd-sized image are dropped at the store)
+    auto load_x = [&](int b, int qa, int q, float4 (&xq)[4]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // taps: (kha, kwa), (kha, 2), (2, kwa), (2, 2) with kha, kwa in {0, 1}: selects, no dynamic indexing
-        const float w_a0 = kha ? wreg[j][3] : wreg[j][0], w_a1 = kha ? wreg[j][4] : wreg[j][1], w_a2 = kha ? wreg[j][5] : wreg[j][2];
-        const float waa = kwa ? w_a1 : w_a0, wab = w_a2;
-        const float wba = kwa ? wreg[j][7] : wreg[j][6], wbb = wreg[j][8];
-        accp[j] = faa * paa[j] * waa + fab * pab[j] * wab + fba * pba[j] * wba + fbb * pbb[j] * wbb;
+      for (int k = 0; k < 4; ++k) {
+        int hi = 2 * qa + (k >> 1), wi = 2 * q + (k & 1);
+        hi = hi < a.H ? hi : a.H - 1; wi = wi < a.W ? wi : a.W - 1;
+        xq[k] = kd_ld4(a.x + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0);
       }
-      if (a.sc) {
-        const float4 xr = kd_ld4(a.x + p * a.C + c0);
-        acc.x *= kd_act_mask(kd_affine(xr.x, sc.x, sh.x), a.act);
-        acc.y *= kd_act_mask(kd_affine(xr.y, sc.y, sh.y), a.act);
-        acc.z *= kd_act_mask(kd_affine(xr.z, sc.z, sh.z), a.act);
-        acc.w *= kd_act_mask(kd_affine(xr.w, sc.w, sh.w), a.act);
-        s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
-        s2.x = fmaf(acc.x, (xr.x - mean.x) * inv.x, s2.x);
-        s2.y = fmaf(acc.y, (xr.y - mean.y) * inv.y, s2.y);
-        s2.z = fmaf(acc.z, (xr.z - mean.z) * inv.z, s2.z);
-        s2.w = fmaf(acc.w, (xr.w - mean.w) * inv.w, s2.w);
+    };
+    for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+      const int q = (int)(it % QW), sg = (int)((it / QW) % nseg), b = (int)(it / ((int64_t)QW * nseg));
+      const int a0 = sg * QSEG, a1 = a0 + QSEG < QH ? a0 + QSEG : QH;
+      const bool w0ok = q < a.Wo, w1ok = q + 1 < a.Wo;
+      float4 d00 = dw_dy_finish(a, dw_dy_raw(a, b, a0, q, c0), a0 < a.Ho && w0ok, al, be, ga, dsc, dsh);
+      float4 d01 = dw_dy_finish(a, dw_dy_raw(a, b, a0, q + 1, c0), a0 < a.Ho && w1ok, al, be, ga, dsc, dsh);
+      // Everything a quad row needs is loaded one iteration AHEAD, i.e. before the previous row's stores are issued:
+      // vmcnt retires in order, so a wait on a load that follows a store would also wait for that store.
+      DwRaw rn0 = dw_dy_raw(a, b, a0 + 1, q, c0), rn1 = dw_dy_raw(a, b, a0 + 1, q + 1, c0);
+      float4 xn[4];
+      if (masked) load_x(b, a0, q, xn);
+      for (int qa = a0; qa < a1; ++qa) {
+        const bool hok = qa + 1 < a.Ho;
+        const float4 d10 = dw_dy_finish(a, rn0, hok && w0ok, al, be, ga, dsc, dsh), d11 = dw_dy_finish(a, rn1, hok && w1ok, al, be, ga, dsc, dsh);
+        float4 xc[4] = {xn[0], xn[1], xn[2], xn[3]};
+        rn0 = dw_dy_raw(a, b, qa + 2, q, c0); rn1 = dw_dy_raw(a, b, qa + 2, q + 1, c0);
+        if (masked) load_x(b, qa + 1 < QH ? qa + 1 : qa, q, xn);
+        float4 g[4];
+        g[0].x = d00.x * wt[4].x; g[0].y = d00.y * wt[4].y; g[0].z = d00.z * wt[4].z; g[0].w = d00.w * wt[4].w;
+        g[1].x = fmaf(d01.x, wt[3].x, d00.x * wt[5].x); g[1].y = fmaf(d01.y, wt[3].y, d00.y * wt[5].y);
+        g[1].z = fmaf(d01.z, wt[3].z, d00.z * wt[5].z); g[1].w = fmaf(d01.w, wt[3].w, d00.w * wt[5].w);
+        g[2].x = fmaf(d10.x, wt[1].x, d00.x * wt[7].x); g[2].y = fmaf(d10.y, wt[1].y, d00.y * wt[7].y);
+        g[2].z = fmaf(d10.z, wt[1].z, d00.z * wt[7].z); g[2].w = fmaf(d10.w, wt[1].w, d00.w * wt[7].w);
+        g[3].x = fmaf(d11.x, wt[0].x, fmaf(d10.x, wt[2].x, fmaf(d01.x, wt[6].x, d00.x * wt[8].x)));
+        g[3].y = fmaf(d11.y, wt[0].y, fmaf(d10.y, wt[2].y, fmaf(d01.y, wt[6].y, d00.y * wt[8].y)));
+        g[3].z = fmaf(d11.z, wt[0].z, fmaf(d10.z, wt[2].z, fmaf(d01.z, wt[6].z, d00.z * wt[8].z)));
+        g[3].w = fmaf(d11.w, wt[0].w, fmaf(d10.w, wt[2].w, fmaf(d01.w, wt[6].w, d00.w * wt[8].w)));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int hi = 2 * qa + (k >> 1), wi = 2 * q + (k & 1);
+          const bool ok = hi < a.H && wi < a.W;
+          float4 v = g[k];
+          if (masked) {
+            const float4 xr = xc[k];
+            v.x *= kd_act_mask(kd_affine(xr.x, sc.x, sh.x), a.act);
+            v.y *= kd_act_mask(kd_affine(xr.y, sc.y, sh.y), a.act);
+            v.z *= kd_act_mask(kd_affine(xr.z, sc.z, sh.z), a.act);
+            v.w *= kd_act_mask(kd_affine(xr.w, sc.w, sh.w), a.act);
+            if (ok) {
+              s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+              s2.x = fmaf(v.x, (xr.x - mean.x) * inv.x, s2.x);
+              s2.y = fmaf(v.y, (xr.y - mean.y) * inv.y, s2.y);
+              s2.z = fmaf(v.z, (xr.z - mean.z) * inv.z, s2.z);
+              s2.w = fmaf(v.w, (xr.w - mean.w) * inv.w, s2.w);
+            }
+          }
+          if (ok) kd_st4(a.gx + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0, v);
+        }
+        d00 = d10; d01 = d11;
       }
-      kd_st4(a.gx + p * a.C + c0, acc);
     }
   }
   if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
