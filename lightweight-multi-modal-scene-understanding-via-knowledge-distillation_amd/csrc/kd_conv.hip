@@ -153,6 +153,26 @@ __device__ __forceinline__ DwRow dw_load_row(const float* __restrict__ x, bool d
   return o;
 }
 
+// the same row in two steps, so that the raw loads of the NEXT row are in flight under the arithmetic of this one
+__device__ __forceinline__ DwRow dw_load_row_raw(const float* __restrict__ x, int b, int hi, int wi, int H, int W, int C, int c0) {
+  const int hic = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
+  const float* rowp = x + ((int64_t)b * H + hic) * W * C + c0;
+  const int wl = wi - 1 < 0 ? 0 : wi - 1, wr_ = wi + 1 >= W ? W - 1 : wi + 1;
+  DwRow o;
+  o.l = kd_ld4(rowp + (int64_t)wl * C); o.c = kd_ld4(rowp + (int64_t)wi * C); o.r = kd_ld4(rowp + (int64_t)wr_ * C);
+  return o;
+}
+__device__ __forceinline__ DwRow dw_finish_row(DwRow r, bool deferred, float4 sc, float4 sh, int act, int hi, int wi, int H, int W) {
+  const bool hok = hi >= 0 && hi < H;
+  const bool lok = hok && wi - 1 >= 0, cok = hok, rok = hok && wi + 1 < W;
+  if (deferred) { r.l = kd_affine_act4(r.l, sc, sh, act); r.c = kd_affine_act4(r.c, sc, sh, act); r.r = kd_affine_act4(r.r, sc, sh, act); }
+  DwRow o;
+  o.l = make_float4(lok ? r.l.x : 0.f, lok ? r.l.y : 0.f, lok ? r.l.z : 0.f, lok ? r.l.w : 0.f);
+  o.c = make_float4(cok ? r.c.x : 0.f, cok ? r.c.y : 0.f, cok ? r.c.z : 0.f, cok ? r.c.w : 0.f);
+  o.r = make_float4(rok ? r.r.x : 0.f, rok ? r.r.y : 0.f, rok ? r.r.z : 0.f, rok ? r.r.w : 0.f);
+  return o;
+}
+
 __device__ __forceinline__ void dw_fma_row(float4& acc, const DwRow& r, const float (*w)[9], int kh) {
   acc.x = fmaf(r.l.x, w[0][kh * 3], fmaf(r.c.x, w[0][kh * 3 + 1], fmaf(r.r.x, w[0][kh * 3 + 2], acc.x)));
   acc.y = fmaf(r.l.y, w[1][kh * 3], fmaf(r.c.y, w[1][kh * 3 + 1], fmaf(r.r.y, w[1][kh * 3 + 2], acc.y)));
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(256) void dw_fwd_sw_kernel(DwArgs a) {
       const int wi = wo * STRIDE;
       DwRow r0 = dw_load_row(a.x, deferred, sc, sh, a.act, b, h0 * STRIDE - 1, wi, a.H, a.W, a.C, c0), r1, r2;
       if (STRIDE == 1) r1 = dw_load_row(a.x, deferred, sc, sh, a.act, b, h0, wi, a.H, a.W, a.C, c0);
-      for (int ho = h0; ho < h1; ++ho) {
+      for (int ho = h0; ho < h1; ++ho) {         // (a one-row-ahead prefetch, as in the backward kernels, measured no gain here)
         if (STRIDE == 2) r1 = dw_load_row(a.x, deferred, sc, sh, a.act, b, 2 * ho, wi, a.H, a.W, a.C, c0);
         r2 = dw_load_row(a.x, deferred, sc, sh, a.act, b, ho * STRIDE + 1, wi, a.H, a.W, a.C, c0);
         float4 acc = kd_zero4();
@@ -214,6 +234,28 @@ __global__ __launch_bounds__(256) void dw_fwd_sw_kernel(DwArgs a) {
     }
   }
   if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
+}
+
+struct DwRaw { float4 d, y; };
+// raw (D, Y) at output pixel (ho, wo), indices clamped into the image (the caller zero-selects what was outside)
+__device__ __forceinline__ DwRaw dw_dy_raw_s1(const DwBwdArgs& a, int b, int ho, int wo, int c0) {
+  const int hoc = ho < 0 ? 0 : (ho >= a.Ho ? a.Ho - 1 : ho), woc = wo < 0 ? 0 : (wo >= a.Wo ? a.Wo - 1 : wo);
+  const int64_t q = (((int64_t)b * a.Ho + hoc) * a.Wo + woc) * a.C + c0;
+  DwRaw r;
+  r.d = kd_ld4(a.D + q);
+  r.y = kd_ld4((a.al ? a.Y : a.D) + q);
+  return r;
+}
+__device__ __forceinline__ float4 dw_dy_finish(const DwBwdArgs& a, DwRaw r, bool ok, float4 al, float4 be, float4 ga, float4 dsc,
+                                               float4 dsh) {
+  float4 v = r.d;
+  if (a.al) {
+    v.x = kd_bwd_operand(r.d.x, r.y.x, al.x, be.x, ga.x, dsc.x, dsh.x, a.d_act);
+    v.y = kd_bwd_operand(r.d.y, r.y.y, al.y, be.y, ga.y, dsc.y, dsh.y, a.d_act);
+    v.z = kd_bwd_operand(r.d.z, r.y.z, al.z, be.z, ga.z, dsc.z, dsh.z, a.d_act);
+    v.w = kd_bwd_operand(r.d.w, r.y.w, al.w, be.w, ga.w, dsc.w, dsh.w, a.d_act);
+  }
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
 // dyeff row (ho, wo-1..wo+1), zero outside the output image
@@ -260,15 +302,27 @@ __global__ __launch_bounds__(256) void dw_bwd_data_sw_kernel(DwBwdArgs a) {
       const int h0 = sg * DW_SEG, h1 = h0 + DW_SEG < a.H ? h0 + DW_SEG : a.H;
       DwRow r0 = dw_load_dy_row(a, al, be, ga, dsc, dsh, b, h0 - 1, wi, c0);
       DwRow r1 = dw_load_dy_row(a, al, be, ga, dsc, dsh, b, h0, wi, c0), r2;
+      // One row AHEAD: the raw dy row hi + 1 (three columns x (D, Y)) and x(hi) are loaded before the store of row
+      // hi - 1 is issued -- vmcnt retires in order, so a wait on a load that FOLLOWS a store also waits for the store.
+      DwRaw nl = dw_dy_raw_s1(a, b, h0 + 1, wi - 1, c0), nc = dw_dy_raw_s1(a, b, h0 + 1, wi, c0), nr = dw_dy_raw_s1(a, b, h0 + 1, wi + 1, c0);
+      float4 xn = kd_zero4();
+      if (a.sc) xn = kd_ld4(a.x + (((int64_t)b * a.H + h0) * a.W + wi) * a.C + c0);
       for (int hi = h0; hi < h1; ++hi) {
-        r2 = dw_load_dy_row(a, al, be, ga, dsc, dsh, b, hi + 1, wi, c0);
+        {
+          const bool hok = hi + 1 < a.Ho;
+          r2.l = dw_dy_finish(a, nl, hok && wi - 1 >= 0, al, be, ga, dsc, dsh);
+          r2.c = dw_dy_finish(a, nc, hok, al, be, ga, dsc, dsh);
+          r2.r = dw_dy_finish(a, nr, hok && wi + 1 < a.Wo, al, be, ga, dsc, dsh);
+        }
+        const float4 xr = xn;
+        nl = dw_dy_raw_s1(a, b, hi + 2, wi - 1, c0); nc = dw_dy_raw_s1(a, b, hi + 2, wi, c0); nr = dw_dy_raw_s1(a, b, hi + 2, wi + 1, c0);
+        if (a.sc) xn = kd_ld4(a.x + (((int64_t)b * a.H + (hi + 1 < a.H ? hi + 1 : hi)) * a.W + wi) * a.C + c0);
         float4 acc = kd_zero4();
         dw_fma_row(acc, r0, wf, 0);
         dw_fma_row(acc, r1, wf, 1);
         dw_fma_row(acc, r2, wf, 2);
         const int64_t p = ((int64_t)b * a.H + hi) * a.W + wi;
         if (a.sc) {
-          const float4 xr = kd_ld4(a.x + p * a.C + c0);
           acc.x *= kd_act_mask(kd_affine(xr.x, sc.x, sh.x), a.act);
           acc.y *= kd_act_mask(kd_affine(xr.y, sc.y, sh.y), a.act);
           acc.z *= kd_act_mask(kd_affine(xr.z, sc.z, sh.z), a.act);
@@ -294,7 +348,6 @@ __global__ __launch_bounds__(256) void dw_bwd_data_sw_kernel(DwBwdArgs a) {
 // so sliding down the quad rows costs TWO new dy values per four input pixels (the per-pixel form loaded and
 // BN-transformed four candidates per pixel: 8x the loads and arithmetic of this one).  Loads are branch-free
 // (clamped addresses, zero selects).
-struct DwRaw { float4 d, y; };
 __device__ __forceinline__ DwRaw dw_dy_raw(const DwBwdArgs& a, int b, int ho, int wo, int c0) {   // clamped, no branches
   const int hoc = ho < a.Ho ? ho : a.Ho - 1, woc = wo < a.Wo ? wo : a.Wo - 1;
   const int64_t q = (((int64_t)b * a.Ho + hoc) * a.Wo + woc) * a.C + c0;
@@ -303,18 +356,6 @@ __device__ __forceinline__ DwRaw dw_dy_raw(const DwBwdArgs& a, int b, int ho, in
   r.y = kd_ld4((a.al ? a.Y : a.D) + q);
   return r;
 }
-__device__ __forceinline__ float4 dw_dy_finish(const DwBwdArgs& a, DwRaw r, bool ok, float4 al, float4 be, float4 ga, float4 dsc,
-                                               float4 dsh) {
-  float4 v = r.d;
-  if (a.al) {
-    v.x = kd_bwd_operand(r.d.x, r.y.x, al.x, be.x, ga.x, dsc.x, dsh.x, a.d_act);
-    v.y = kd_bwd_operand(r.d.y, r.y.y, al.y, be.y, ga.y, dsc.y, dsh.y, a.d_act);
-    v.z = kd_bwd_operand(r.d.z, r.y.z, al.z, be.z, ga.z, dsc.z, dsh.z, a.d_act);
-    v.w = kd_bwd_operand(r.d.w, r.y.w, al.w, be.w, ga.w, dsc.w, dsh.w, a.d_act);
-  }
-  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-}
-
 __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(DwBwdArgs a) {
   __shared__ float red[2 * 256 * 4];
   const int tid = threadIdx.x;
@@ -434,11 +475,22 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_sw_kernel(DwBwdArgs a) {
       const int wi = wo * STRIDE;
       DwRow r0 = dw_load_row(a.x, deferred, sc, sh, a.act, b, h0 * STRIDE - 1, wi, a.H, a.W, a.C, c0), r1, r2;
       if (STRIDE == 1) r1 = dw_load_row(a.x, deferred, sc, sh, a.act, b, h0, wi, a.H, a.W, a.C, c0);
+      // the raw operands of row ho + 1 are loaded before row ho is accumulated (27 x 4 FMAs hide the latency)
+      DwRow n1, n2;
+      if (STRIDE == 2) n1 = dw_load_row_raw(a.x, b, 2 * h0, wi, a.H, a.W, a.C, c0);
+      n2 = dw_load_row_raw(a.x, b, h0 * STRIDE + 1, wi, a.H, a.W, a.C, c0);
+      DwRaw nd = dw_dy_raw(a, b, h0, wo, c0);
       for (int ho = h0; ho < h1; ++ho) {
-        if (STRIDE == 2) r1 = dw_load_row(a.x, deferred, sc, sh, a.act, b, 2 * ho, wi, a.H, a.W, a.C, c0);
-        r2 = dw_load_row(a.x, deferred, sc, sh, a.act, b, ho * STRIDE + 1, wi, a.H, a.W, a.C, c0);
-        const float4 d = dw_dyeff(a, ((int64_t)b * a.Ho + ho) * a.Wo + wo, c0, al, be, ga, dsc, dsh);
-#define KD_DW_WG(KH, R)                                                                                     \
+        if (STRIDE == 2) r1 = dw_finish_row(n1, deferred, sc, sh, a.act, 2 * ho, wi, a.H, a.W);
+        r2 = dw_finish_row(n2, deferred, sc, sh, a.act, ho * STRIDE + 1, wi, a.H, a.W);
+        const float4 d = dw_dy_finish(a, nd, true, al, be, ga, dsc, dsh);
+        {
+          const int hn = ho + 1 < a.Ho ? ho + 1 : ho;      // clamped: the prefetch after the last row is discarded
+          if (STRIDE == 2) n1 = dw_load_row_raw(a.x, b, 2 * hn, wi, a.H, a.W, a.C, c0);
+          n2 = dw_load_row_raw(a.x, b, hn * STRIDE + 1, wi, a.H, a.W, a.C, c0);
+          nd = dw_dy_raw(a, b, hn, wo, c0);
+        }
+#define KD_DW_WG(KH, R)                                                                                    \
   acc[KH * 3 + 0].x = fmaf(d.x, R.l.x, acc[KH * 3 + 0].x); acc[KH * 3 + 0].y = fmaf(d.y, R.l.y, acc[KH * 3 + 0].y); \
   acc[KH * 3 + 0].z = fmaf(d.z, R.l.z, acc[KH * 3 + 0].z); acc[KH * 3 + 0].w = fmaf(d.w, R.l.w, acc[KH * 3 + 0].w); \
   acc[KH * 3 + 1].x = fmaf(d.x, R.c.x, acc[KH * 3 + 1].x); acc[KH * 3 + 1].y = fmaf(d.y, R.c.y, acc[KH * 3 + 1].y); \
