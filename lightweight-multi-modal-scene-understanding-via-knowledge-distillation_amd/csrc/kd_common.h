@@ -84,11 +84,7 @@ __device__ __forceinline__ float kd_bwd_operand(float d, float x, float al, floa
 // drain vmcnt to 0 first: every global load still in flight (register prefetch) and, worse, every global STORE
 // already issued is waited for at each barrier (~2-3 us per drained store burst in the GEMM epilogue).  Use this one
 // wherever the barrier only protects an LDS image; threads here never communicate through global memory.
-#ifdef KD_DBG_SYNCTHREADS
-__device__ __forceinline__ void kd_lds_barrier() { __syncthreads(); }
-#else
 __device__ __forceinline__ void kd_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
 
 // LiDAR point-MLP layer 0 (Conv1d 4 -> C, lidar_encoder.py:26): ONE evaluation order, used by the statistics pass and
 // by every kernel that recomputes the layer from the 16-byte point instead of reading its [P, C] output from HBM, so a

@@ -18,6 +18,8 @@ namespace {
 
 std::atomic<int> g_gemm_split{0};
 
+// Dev build only (-DKD_DBG_PHASES [-DKD_DBG_EPI]): per-phase clock64() totals of wave 0 of every workgroup, read back by
+// tools/bench_gemm through kd_dbg_read -- how the epilogue store drains and the per-K-tile serialisation were found.
 #ifdef KD_DBG_PHASES
 __device__ unsigned long long kd_dbg_counters[8];
 #define KD_STAMP(i) do { const long long t_ = clock64(); ph_acc[i] += t_ - ph_t; ph_t = t_; } while (0)
@@ -163,9 +165,6 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
     for (int i = 0; i < AF; ++i) {
       int64_t gm = m0 + (tid >> 3) + 32 * i;
       gm = gm < g.M ? gm : (int64_t)g.M - 1;
-#ifdef KD_DBG_NOLDG
-      gm = (tid >> 3) + 32 * i;
-#endif
       if (PRO == 3) {
         if (kt == 0) rx[i] = kd_ld4(g.A + gm * 4);      // the point: the same row for every K-tile
       } else {
@@ -265,11 +264,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
         // smallest terms first; the four accumulators separate two uses of the same one by 3 other MFMAs
         constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-#ifdef KD_DBG_NOMFMA
-        for (int t = 0; t < 1; ++t)
-#else
         for (int t = 0; t < 6; ++t)
-#endif
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -465,11 +460,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
           s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
         }
       }
-#ifndef KD_DBG_NOSTORE
       if (ok) kd_st4(g.C + row * g.ldc + col, v);
-#else
-      if (ok && v.x == 12345.678f) kd_st4(g.C + row * g.ldc + col, v);
-#endif
     }
   }
   if (EPI != 0) {
