@@ -186,9 +186,10 @@ class _RawFrames(Dataset):
 class DeviceBatchLoader:
     """DataLoader over raw host frames (any num_workers) + per-batch device preparation in the consumer."""
 
-    def __init__(self, ds: PandaSetDataset, batch_size: int, shuffle: bool, num_workers: int):
+    def __init__(self, ds: PandaSetDataset, batch_size: int, shuffle: bool, num_workers: int, to_cpu: bool = False):
         self.dataset = ds
         self.batch_size = batch_size
+        self.to_cpu = to_cpu
         self._loader = DataLoader(_RawFrames(ds), batch_size=batch_size, shuffle=shuffle, num_workers=num_workers,
                                   collate_fn=list)
 
@@ -197,7 +198,10 @@ class DeviceBatchLoader:
 
     def __iter__(self):
         for raws in self._loader:
-            yield self.dataset.prepare_batch(raws)
+            b = self.dataset.prepare_batch(raws)
+            if self.to_cpu:                 # for host-side analysis scripts that call .numpy() on the batch tensors
+                b = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.items()}
+            yield b
 
 
 class SyntheticPandaSet(Dataset):
@@ -221,12 +225,17 @@ class SyntheticPandaSet(Dataset):
 
 
 def create_pandaset_dataloaders(root: str, train_scenes: List[str], val_scenes: List[str], batch_size: int = 4,
-                                num_workers: int = 0, verbose: bool = True):
+                                num_workers: int = 0, verbose: bool = True, to_cpu: bool = None):
+    """Reference signature (pandaset_dataset.py:144-160) plus `to_cpu`: batches stay on the GPU by default (the trainers'
+    `.to(device)` is then free); to_cpu=True (or KD_LOADER_TO_CPU=1) returns host tensors for the reference's analysis
+    scripts, which call `.numpy()` on them (test_dataset_distribution.py:22, verify_2class_distribution.py)."""
+    if to_cpu is None:
+        to_cpu = os.environ.get("KD_LOADER_TO_CPU") == "1"
     if os.path.isdir(root):
         train_ds = PandaSetDataset(root, train_scenes, verbose=verbose)
         val_ds = PandaSetDataset(root, val_scenes, verbose=verbose)
-        return (DeviceBatchLoader(train_ds, batch_size, shuffle=True, num_workers=num_workers),
-                DeviceBatchLoader(val_ds, batch_size, shuffle=False, num_workers=num_workers))
+        return (DeviceBatchLoader(train_ds, batch_size, shuffle=True, num_workers=num_workers, to_cpu=to_cpu),
+                DeviceBatchLoader(val_ds, batch_size, shuffle=False, num_workers=num_workers, to_cpu=to_cpu))
     if verbose:
         print(f"[data] '{root}' not found: serving synthetic PandaSet-shaped frames")
     train = SyntheticPandaSet(n_frames=max(8, 8 * len(train_scenes)), seed=1)

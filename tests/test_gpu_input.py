@@ -113,6 +113,11 @@ def test_pandaset_dataset_matches_reference_reader(tmp_path):
     assert b["sample_token"] == ["002_00", "002_01"]
     for j in range(2):
         assert np.array_equal(b["segmentation"][j].cpu().numpy(), g[f"{2 + j}/segmentation"])
+    # host-tensor mode for the reference's analysis scripts (they call .numpy() on the batch)
+    _, vl_cpu = create_pandaset_dataloaders(str(tmp_path), scenes[:1], scenes[1:], batch_size=2, num_workers=0, verbose=False,
+                                            to_cpu=True)
+    bc = next(iter(vl_cpu))
+    assert not bc["image"].is_cuda and np.array_equal(bc["segmentation"].numpy(), b["segmentation"].cpu().numpy())
 
 
 def test_trainer_consumes_device_loader(tmp_path):
