@@ -282,3 +282,14 @@ def test_x4_model_matches_reference_fixture():
     assert z.shape == (2, 3, 64, 64)
     ref = torch.from_numpy(gd["logits"])
     assert (z.cpu() - ref).abs().max().item() < max(1e-4, 5e-6 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("h,w,stride", [(9, 6, 2), (5, 11, 2), (6, 9, 1), (1, 7, 2), (33, 2, 2)])
+def test_inverted_residual_non_square(h, w, stride):
+    """Depthwise kernels on non-square / odd / degenerate maps (quad form of the stride-2 data gradient, 16-row segments)."""
+    from src.models.camera_encoder import InvertedResidual
+    torch.manual_seed(0)
+    m = InvertedResidual(32, 64, stride=stride, expansion_ratio=6)
+    x = torch.randn(2, 32, h, w, generator=torch.Generator().manual_seed(h * 100 + w))
+    _compare(m, lambda xx, st: O.inverted_residual(xx, {("." + k): v for k, v in st.items()}, "", 32, 64, stride, 6, True), x,
+             seed=h + w)
