@@ -67,9 +67,15 @@ struct GemmArgs {
 // each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (32 cycles for K = 16
 // against 8 x 64 cycles of v_mfma_f32_32x32x2_f32): 6 x 32 = 192 cycles per 32x32x16 block instead of 512, so the
 // near-ridge shapes of this network (AI 14..64 FLOP/B) become HBM-bound instead of matrix-pipe-bound.
-// LDS image: 3 planes per operand, rows of 32 bf16 padded to 40 (80 B: 16 consecutive rows x 16 B hit 64 banks once).
+// (LDS image of the split operands: see SPROW below.)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-constexpr int SPLD = 40;                                // bf16 per LDS row in the split image
+// Split LDS image: [plane][row][32 bf16], rows of exactly 64 bytes, no padding, with the four 16-byte chunks of a
+// row XOR-swizzled by (row >> 2) & 3.  ds_read_b128 is served in lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (and
+// the same +32): the four rows of a group that share row % 4 then land in four different chunks, so the 16 lanes tile
+// the 64 banks exactly once; a 16-lane ds_write_b64 group covers two whole rows = 32 consecutive words.  Both access
+// kinds are conflict-free and the image is 20 % smaller than with padded rows (49 KB for 128x128: 3 workgroups / CU).
+constexpr int SPROW = 32;                               // bf16 per row
+__device__ __forceinline__ int kd_sw_chunk(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 8; }   // element offset
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -93,15 +99,19 @@ __device__ __forceinline__ void kd_split3(float4 v, uint2& hi, uint2& mid, uint2
 }
 
 template <int PRO, int EPI, int WM, int WN, bool SPLIT>
-__global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) void pw_gemm_kernel(GemmArgs g) {
+// Occupancy: 3 workgroups / CU wherever 168 registers and 3 x 49 KB of LDS allow it (fp32: all but the 256x64 PRO2
+// kernel; split: the 128x128 kernels except PRO2, whose two-tensor prologue would spill 46 registers).  The third
+// workgroup is worth 8-12 % on the forward kernels: these loops are latency-bound, not pipe-bound (PMC: matrix pipe
+// busy ~31 %, VALU ~10 %, LDS ~22 % at 2 workgroups / CU).
+__global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2) ? 3 : 2) : ((PRO == 2 && WM == 4) ? 2 : 3)) void pw_gemm_kernel(GemmArgs g) {
   constexpr int BMt = 64 * WM, BNt = 64 * WN;
   constexpr int AF = BMt / 32, BF = BNt / 32;          // float4 loads per thread per K-tile
-  constexpr int SMEM_FLOATS = SPLIT ? (BMt + BNt) * 3 * SPLD / 2 : (BMt + BNt) * LDSLD;
+  constexpr int SMEM_FLOATS = SPLIT ? (BMt + BNt) * 3 * SPROW / 2 : (BMt + BNt) * LDSLD;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   float* As = smem;
   float* Bs = smem + BMt * LDSLD;
   unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);          // split image: A planes then B planes
-  unsigned short* Bh = Ah + 3 * BMt * SPLD;
+  unsigned short* Bh = Ah + 3 * BMt * SPROW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int nct = (g.N + BNt - 1) / BNt;
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
   // MFMAs of the previous tile.  Per-channel coefficients depend only on (k0, tid & 7).
   // PF2: a second register stage for the operand tiles (split arithmetic, 128x128 tile, PRO 0/1): the matrix work
   // of one K-tile (~0.6 us) is shorter than the HBM latency under load, so two K-tiles of loads are kept in flight.
-  constexpr bool PF2 = SPLIT && PRO < 2 && WM == 2;
+  constexpr bool PF2 = false;   // (a second register stage costs the third workgroup per CU, which is worth more)
   // Per-channel coefficients travel WITH their tile (loaded just before it): a coefficient load issued later than
   // a prefetch would sit behind it in the in-order vmcnt queue and drain the prefetch when first used.  Only the
   // fp32 PRO2 kernel (170-register budget at 3 workgroups/CU) fetches its five vectors at the point of use.
@@ -225,19 +235,21 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
       for (int i = 0; i < AF; ++i) {
         uint2 hi, mid, lo;
         kd_split3(ra[i], hi, mid, lo);
-        unsigned short* d = Ah + ((tid >> 3) + 32 * i) * SPLD + c4 * 4;
+        const int row = (tid >> 3) + 32 * i;
+        unsigned short* d = Ah + row * SPROW + kd_sw_chunk(row, c4 >> 1) + (c4 & 1) * 4;
         *reinterpret_cast<uint2*>(d) = hi;
-        *reinterpret_cast<uint2*>(d + BMt * SPLD) = mid;
-        *reinterpret_cast<uint2*>(d + 2 * BMt * SPLD) = lo;
+        *reinterpret_cast<uint2*>(d + BMt * SPROW) = mid;
+        *reinterpret_cast<uint2*>(d + 2 * BMt * SPROW) = lo;
       }
 #pragma unroll
       for (int i = 0; i < BF; ++i) {
         uint2 hi, mid, lo;
         kd_split3(rb[i], hi, mid, lo);
-        unsigned short* d = Bh + ((tid >> 3) + 32 * i) * SPLD + c4 * 4;
+        const int row = (tid >> 3) + 32 * i;
+        unsigned short* d = Bh + row * SPROW + kd_sw_chunk(row, c4 >> 1) + (c4 & 1) * 4;
         *reinterpret_cast<uint2*>(d) = hi;
-        *reinterpret_cast<uint2*>(d + BNt * SPLD) = mid;
-        *reinterpret_cast<uint2*>(d + 2 * BNt * SPLD) = lo;
+        *reinterpret_cast<uint2*>(d + BNt * SPROW) = mid;
+        *reinterpret_cast<uint2*>(d + 2 * BNt * SPROW) = lo;
       }
     } else {
 #pragma unroll
@@ -253,13 +265,13 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : ((PRO == 2 && WM == 4) ? 2 : 3)) v
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 a[2][3], b[2][3];
-        const int ko = ks * 16 + (lane >> 5) * 8;
+        const int ko = kd_sw_chunk(lane & 31, ks * 2 + (lane >> 5));     // row bits 2..3 == lane bits 2..3 (tile offsets are multiples of 32)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int p = 0; p < 3; ++p) {
-            a[i][p] = *reinterpret_cast<const bf16x8*>(Ah + (p * BMt + wr * 64 + i * 32 + (lane & 31)) * SPLD + ko);
-            b[i][p] = *reinterpret_cast<const bf16x8*>(Bh + (p * BNt + wc * 64 + i * 32 + (lane & 31)) * SPLD + ko);
+            a[i][p] = *reinterpret_cast<const bf16x8*>(Ah + (p * BMt + wr * 64 + i * 32 + (lane & 31)) * SPROW + ko);
+            b[i][p] = *reinterpret_cast<const bf16x8*>(Bh + (p * BNt + wc * 64 + i * 32 + (lane & 31)) * SPROW + ko);
           }
         // smallest terms first; the four accumulators separate two uses of the same one by 3 other MFMAs
         constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
