@@ -178,7 +178,8 @@ def main():
             "num_classes": 2, "gemm_arithmetic": ("fp32 operands as 3 bf16 pieces, 6 piece products on the bf16 matrix pipe, fp32 accumulate (fp32-grade)"
                                                    if ops.get_gemm_arithmetic() == "split" else "exact fp32 MFMA products"),
             "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-            "parallelism": f"dp{world}" + (" (bucketed RCCL all-reduce overlapped with backward)" if world > 1 else "")},
+            "parallelism": f"dp{world}" + (" (bucketed RCCL all-reduce overlapped with backward)" if world > 1 else ""),
+            "peak_hbm_gib_per_gpu": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)},
     }
 
     if not args.no_roofline:
