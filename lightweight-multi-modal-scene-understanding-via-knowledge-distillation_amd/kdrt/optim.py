@@ -11,7 +11,6 @@ from typing import Iterable, List
 
 import torch
 
-from . import ops
 from .lib import lib
 from .ops import P, stream
 

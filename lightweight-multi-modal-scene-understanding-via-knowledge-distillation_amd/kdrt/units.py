@@ -16,7 +16,7 @@ import torch
 
 from . import gradsink, ops
 from .lib import KDError, lib
-from .ops import ACT_NONE, ACT_RELU, ACT_RELU6, BNC, Operand, P, ld, stream
+from .ops import ACT_NONE, ACT_RELU, BNC, Operand, P, ld, stream
 
 
 class UnitSpec:

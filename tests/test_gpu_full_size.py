@@ -12,7 +12,6 @@ pytestmark = pytest.mark.gpu
 def test_duplicated_batch_invariance_at_bench_size():
     if torch.cuda.get_device_properties(0).total_memory < 100 * 2 ** 30:
         pytest.skip("needs an MI355X-class HBM")
-    import kd_oracle as O
     from _gpu_util import build_product, load_random_state
     from kdrt.losses import kd_objective
     dev = torch.device("cuda")
