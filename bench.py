@@ -102,9 +102,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    # 128 frames/GPU: the throughput batch SURVEY.md section 8d names (the reference's B=4 is launch-bound);
-    # measured on one MI355X: 16 -> 1342, 32 -> 1518, 64 -> 1606, 128 -> 1666 frames/s
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("KD_BENCH_BATCH", 128)), help="frames per GPU per step")
+    # 256 frames/GPU: the larger of the two throughput batches SURVEY.md section 8d names (the reference's B=4 is
+    # launch-bound); 69.7 GiB of the 288 GB HBM.  Measured on one MI355X (final kernels): 4 -> 677 (907 under hipGraph
+    # replay), 32 -> 1960, 64 -> 2100, 128 -> 2260, 256 -> 2307 frames/s
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("KD_BENCH_BATCH", 256)), help="frames per GPU per step")
     ap.add_argument("--points", type=int, default=80000)
     ap.add_argument("--image", type=int, default=256)
     ap.add_argument("--grid", type=int, default=64)
@@ -196,16 +197,23 @@ def main():
         recs, ops.PROFILE = ops.PROFILE, None
         agg = {}
         torch.cuda.synchronize()
+        arith = ops.get_gemm_arithmetic()
+        # per-launch roofline floor: max(matrix-pipe time, HBM time) with the pipe peak of the arithmetic in use
+        # (split: 6 bf16 MFMA products per fp32 product -> 2500 / 6 TFLOP/s fp32-equivalent) and the 8 TB/s HBM peak
+        pipe_peak = (MFMA_BF16_PEAK_TFLOPS / 6.0 if arith == "split" else MFMA_F32_PEAK_TFLOPS) * 1e12
+        groups = {}
         for rec in recs:
-            kind, flops, nbytes, secs = ops.prof_scaled(rec)      # compacted-point launches: actual row count
+            kind, flops, nbytes, secs, M = ops.prof_scaled(rec)      # compacted-point launches: actual row count
             a = agg.setdefault(kind, [0.0, 0.0, 0.0, 0])
             a[0] += flops; a[1] += nbytes; a[2] += secs; a[3] += 1
+            grp = "lidar_point_mlp" if M == args.batch * args.points else "camera_fpn_fusion_head"
+            q = groups.setdefault(grp, [0.0, 0.0, 0.0, 0.0, 0])
+            q[0] += flops; q[1] += nbytes; q[2] += secs; q[3] += max(flops / pipe_peak, nbytes / (HBM_PEAK_GBPS * 1e9)); q[4] += 1
         g = agg.get("pw_gemm", [0, 0, 1e-9, 0])
         w = agg.get("pw_wgrad", [0, 0, 1e-9, 0])
         # The family is HBM-bound since its products moved to the bf16 matrix pipe (bf16x6 split arithmetic): the
         # roofline is algorithmic bytes / launch time against the HBM peak.  The matrix-pipe view is kept beside it:
         # fp32-equivalent FLOP/s (2MKN) and the bf16 FLOP/s actually executed (6 piece products per product).
-        arith = ops.get_gemm_arithmetic()
         gbps = g[1] / g[2] / 1e9
         tf = g[0] / g[2] / 1e12
         out["roofline"] = {
@@ -221,19 +229,27 @@ def main():
             "matrix_pipe": ({"executed_bf16_tflops": round(6 * tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(6 * tf / MFMA_BF16_PEAK_TFLOPS, 4)}
                             if arith == "split" else {"executed_fp32_tflops": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}),
             "gemm_time_share_of_step": round(g[2] / 2 / (elapsed / args.steps), 3),
+            # all GEMM launches (fwd + dgrad + wgrad) by where they sit in the model; frac_of_roofline = sum of per-launch
+            # max(flops / pipe peak, bytes / HBM peak) over the measured time; fp32_mfma_frac = fp32-equivalent FLOP/s / 157.3
+            "by_group": {k: {"launches_per_step": v[4] // 2, "ms_per_step": round(v[2] / 2 * 1e3, 2),
+                             "fp32_equivalent_tflops": round(v[0] / v[2] / 1e12, 1), "algorithmic_GBps": round(v[1] / v[2] / 1e9, 0),
+                             "frac_of_roofline": round(v[3] / v[2], 3),
+                             "fp32_mfma_frac": round(v[0] / v[2] / 1e12 / MFMA_F32_PEAK_TFLOPS, 3)} for k, v in groups.items()},
             "wgrad": {"achieved": round(w[1] / w[2] / 1e9, 1), "unit": "GB/s", "fp32_tflops": round(w[0] / w[2] / 1e12, 2),
                       "launches_per_step": w[3] // 2, "time_share_of_step": round(w[2] / 2 / (elapsed / args.steps), 3)},
         }
         # HBM bytes per launch come from PMC counters, which need their own rocprofv3 passes: use the committed
         # measurement of this exact workload (profiles/), null for any other configuration
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic_B128.json")))
-            wl = pmc["workload"]
-            if (wl["per_gpu_batch"], wl["points_per_frame"], wl["image"], wl["bev_grid"]) == (args.batch, args.points, args.image, args.grid):
-                out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_bench_pmc_traffic_B128.json)"
-        except (OSError, KeyError, ValueError):
-            pass
+        for fn in ("r01_bench_pmc_traffic_B256.json", "r01_bench_pmc_traffic_B128.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                wl = pmc["workload"]
+                if (wl["per_gpu_batch"], wl["points_per_frame"], wl["image"], wl["bev_grid"]) == (args.batch, args.points, args.image, args.grid):
+                    out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_unit"] = f"bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/{fn})"
+                    break
+            except (OSError, KeyError, ValueError):
+                continue
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(teacher, student, args.points, args.image, args.grid)
     if rank == 0:

@@ -153,10 +153,11 @@ def _prof_end(e0, kind, flops, nbytes, m_dev=None, M=None):
 
 
 def prof_scaled(rec):
-    """(kind, flops, bytes, seconds) of one PROFILE record, row-count corrected (call after a device synchronise)."""
+    """(kind, flops, bytes, seconds, M) of one PROFILE record, row-count corrected (call after a device synchronise);
+    M is the nominal row count of the launch (lets the reader tell point-MLP launches from image-grid ones)."""
     kind, flops, nbytes, e0, e1, m_dev, M = rec
     f = 1.0 if m_dev is None else min(int(m_dev.item()), M) / float(M)
-    return kind, flops * f, nbytes * f, e0.elapsed_time(e1) * 1e-3
+    return kind, flops * f, nbytes * f, e0.elapsed_time(e1) * 1e-3, M
 
 
 def pw_gemm(A, W, C_out, *, M, K, N, A2=None, pro=0, pro_act=0, p=(None,) * 5, bias=None, addend=None, epi=0,
@@ -196,7 +197,7 @@ def l1_dgrad(t, y, Wt, gin, *, op: Operand, al, be, ga, msc, msh, mact, partial)
     e0 = _prof_begin()
     lib.call("kd_lidar_l1_dgrad", P(t), ld(t), P(y), ld(y), P(al), P(be), P(ga), P(msc), P(msh), mact, P(Wt), P(gin), ld(gin),
              P(pts), P(w0), P(b0), P(op.sc), P(op.sh), P(op.bnc.mean), P(op.bnc.invstd), op.act, P(partial), M, N1, K0, stream())
-    _prof_end(e0, "pw_gemm", 2.0 * M * N1 * K0, 4.0 * (2 * M * N1 + M * K0 + M * 4 + N1 * K0))
+    _prof_end(e0, "pw_gemm", 2.0 * M * N1 * K0, 4.0 * (2 * M * N1 + M * K0 + M * 4 + N1 * K0), None, M)
 
 
 def l1_wgrad(t, y, dW, *, op: Operand, al, be, ga, msc, msh, mact):
@@ -207,7 +208,7 @@ def l1_wgrad(t, y, dW, *, op: Operand, al, be, ga, msc, msh, mact):
     e0 = _prof_begin()
     lib.call("kd_lidar_l1_wgrad", P(t), ld(t), P(y), ld(y), mact, P(al), P(be), P(ga), P(msc), P(msh), P(pts), P(w0), P(b0),
              P(op.sc), P(op.sh), op.act, P(dW), M, N, K, P(ws), nbytes, stream())
-    _prof_end(e0, "pw_wgrad", 2.0 * M * N * K, 4.0 * (2 * M * N + M * 4 + N * K))
+    _prof_end(e0, "pw_wgrad", 2.0 * M * N * K, 4.0 * (2 * M * N + M * 4 + N * K), None, M)
 
 
 def pw_wgrad(D, A, dW, *, M, N, K, X=None, d_mode=0, d_act=0, al=None, be=None, ga=None, msc=None, msh=None,
@@ -217,7 +218,7 @@ def pw_wgrad(D, A, dW, *, M, N, K, X=None, d_mode=0, d_act=0, al=None, be=None, 
     e0 = _prof_begin()
     lib.call("kd_pwconv_wgrad", P(D), ld(D), P(X), ld(X) if X is not None else 0, d_mode, d_act, P(al), P(be), P(ga),
              P(msc), P(msh), P(A), ld(A), a_mode, a_act, P(asc), P(ash), P(dW), M, N, K, P(ws), nbytes, stream())
-    _prof_end(e0, "pw_wgrad", 2.0 * M * N * K, 4.0 * (M * N * (2 if d_mode == 2 else 1) + M * K + N * K))
+    _prof_end(e0, "pw_wgrad", 2.0 * M * N * K, 4.0 * (M * N * (2 if d_mode == 2 else 1) + M * K + N * K), None, M)
 
 
 def transpose(w2d: torch.Tensor) -> torch.Tensor:
