@@ -144,6 +144,20 @@ int kd_lidar_scatter_max_bwd(const float* pts, const float* y, const float* sc, 
                              float y0, float y1, void* ws, size_t ws_bytes, void* stream);
 int kd_lidar_bev_index(const float* pts, int* cell, int64_t P, int H, int W, float x0, float x1, float y0,
                        float y1, void* stream);
+/* training path of the same scatter-max (lidar_encoder.py:57-99), atomic-free: bin the point ids by grid row
+ * once (counting sort), then one wave per row takes the max / counts the ties / splits the gradient.
+ * row_of_point[B*N] = b*H*W + cell or -1; seg_start[B*H*W + 1]; perm[B*N] (first seg_start[B*H*W] entries used).
+ * Same results as kd_lidar_scatter_max_fwd / _bwd (bit-identical grid and G).  C must be 64, 128 or 256. */
+size_t kd_lidar_cell_sort_ws_bytes(int B, int64_t N, int H, int W);
+int kd_lidar_cell_sort(const float* pts, int B, int64_t N, int H, int W, float x0, float x1, float y0, float y1,
+                       int* row_of_point, int* seg_start, int* perm, void* ws, size_t ws_bytes, void* stream);
+int kd_lidar_seg_max_fwd(const float* y, const float* sc, const float* sh, int act, const int* seg_start,
+                         const int* perm, float* grid, int64_t ncells, int C, void* stream);
+int64_t kd_lidar_seg_stat_rows(int64_t ncells);
+int kd_lidar_seg_max_bwd(const float* y, const float* sc, const float* sh, int act, const float* grid,
+                         const float* dout, const float* mean, const float* invstd, const int* seg_start,
+                         const int* perm, const int* row_of_point, float* G, float* partial, int64_t P,
+                         int64_t ncells, int C, void* stream);
 /* inference-only: compact the in-range points (arbitrary order) with their flat (batch, cell) row; `counter`
  * (one device int, zeroed here) receives the count.  Then scatter-max over the pre-binned rows. */
 int kd_lidar_compact(const float* pts, float* out_pts, int* out_cell, int* counter, int B, int64_t N, int H, int W,

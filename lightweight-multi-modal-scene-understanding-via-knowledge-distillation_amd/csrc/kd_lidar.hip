@@ -395,3 +395,350 @@ int kd_lidar_scatter_max_idx_fwd(const float* y, const float* sc, const float* s
 }
 
 }  // extern "C"
+
+// ---- cell-sorted (segmented) scatter-max: the training path --------------------------------------
+// The atomic scatter above costs an atomic RMW stream forward and two more sweeps (tie count, then
+// gradient) backward.  Training instead bins the point ids by grid row once per step (counting sort:
+// histogram with the atomic's return value as the in-cell rank, exclusive scan, fill) and then walks
+// each cell's points with ONE wave: the max, the tie count and the gradient split are plain register
+// work, every grid row is written exactly once (no memset, no atomics) and the tie counts never touch
+// memory.  The in-cell order is arbitrary (atomic rank) but max, tie count and the per-point gradient do
+// not depend on it, and the BN-backward sums see at most one distinct term per (cell, channel) (tied
+// holders contribute identical terms), so results stay bitwise run-to-run deterministic.
+namespace {
+
+constexpr int SCAN_CHUNK = 2048;   // elements per 256-thread block (8 per thread)
+
+__global__ void seg_count_kernel(const float* __restrict__ pts, int* __restrict__ row_of_point, int* __restrict__ rank,
+                                 int* counts, int64_t P, int64_t N, BevGeom g) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int c;
+  if (bev_cell(kd_ld4(pts + p * 4), g, c)) {
+    const int row = (int)(p / N) * (g.H * g.W) + c;
+    row_of_point[p] = row;
+    rank[p] = atomicAdd(counts + row, 1);
+  } else {
+    row_of_point[p] = -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const int* __restrict__ v, int* __restrict__ bsum, int64_t n) {
+  __shared__ int red[256];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+  int s = 0;
+  for (int i = threadIdx.x; i < SCAN_CHUNK; i += 256)
+    if (base + i < n) s += v[base + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+}
+
+// exclusive scan of the block sums, in place; one 1024-thread block walks them in chunks with a carry
+__global__ __launch_bounds__(1024) void scan_bsums_kernel(int* bsum, int nb) {
+  __shared__ int sh[1024];
+  int carry = 0;
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + (int)threadIdx.x;
+    const int v = i < nb ? bsum[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nb) bsum[i] = carry + sh[threadIdx.x] - v;
+    carry += sh[1023];
+    __syncthreads();
+  }
+}
+
+// v[i] <- exclusive prefix of v (in place); thread t of block b owns the 8 consecutive elements at b*2048 + t*8
+__global__ __launch_bounds__(256) void scan_apply_kernel(int* v, const int* __restrict__ bsum, int64_t n) {
+  __shared__ int sh[256];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * 8;
+  int x[8];
+  int tot = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { x[j] = base + j < n ? v[base + j] : 0; tot += x[j]; }
+  sh[threadIdx.x] = tot;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int run = bsum[blockIdx.x] + sh[threadIdx.x] - tot;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (base + j < n) v[base + j] = run;
+    run += x[j];
+  }
+}
+
+__global__ void seg_fill_kernel(const int* __restrict__ row_of_point, const int* __restrict__ rank,
+                                const int* __restrict__ start, int* __restrict__ perm, int64_t P) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int row = row_of_point[p];
+  if (row >= 0) perm[start[row] + rank[p]] = (int)p;
+}
+
+struct SegArgs {
+  const float* y; const float* sc; const float* sh; int act;          // deferred [P, C]
+  const int* start; const int* perm;                                  // [ncells + 1], [P]
+  float* grid; const float* dout; const float* mean; const float* invstd;
+  float* G; float* partial; int64_t ncells; int C;
+};
+
+template <int VEC> struct SegVec;
+template <> struct SegVec<1> { typedef float type; };
+template <> struct SegVec<2> { typedef float2 type; };
+template <> struct SegVec<4> { typedef float4 type; };
+
+template <int VEC> __device__ __forceinline__ void seg_ld(float (&r)[VEC], const float* p) {
+  const typename SegVec<VEC>::type v = *reinterpret_cast<const typename SegVec<VEC>::type*>(p);
+  __builtin_memcpy(r, &v, sizeof(v));
+}
+template <int VEC> __device__ __forceinline__ void seg_st(float* p, const float (&r)[VEC]) {
+  typename SegVec<VEC>::type v;
+  __builtin_memcpy(&v, r, sizeof(v));
+  *reinterpret_cast<typename SegVec<VEC>::type*>(p) = v;
+}
+
+// one wave per grid row; lane l owns channels [l*VEC, l*VEC + VEC)  (C == 64*VEC)
+template <int VEC>
+__global__ __launch_bounds__(256) void seg_max_fwd_kernel(SegArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int c0 = lane * VEC;
+  float sc[VEC], sh[VEC];
+  seg_ld<VEC>(sc, a.sc + c0);
+  seg_ld<VEC>(sh, a.sh + c0);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < a.ncells; row += nw) {
+    const int s = __builtin_amdgcn_readfirstlane(a.start[row]);
+    const int e = __builtin_amdgcn_readfirstlane(a.start[row + 1]);
+    float m[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) m[j] = 0.f;
+    int i = s;
+    for (; i + 4 <= e; i += 4) {
+      float r[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t p = __builtin_amdgcn_readfirstlane(a.perm[i + u]);
+        seg_ld<VEC>(r[u], a.y + p * a.C + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float v = kd_act(kd_affine(r[u][j], sc[j], sh[j]), a.act);
+          m[j] = v > m[j] ? v : m[j];      // +0 start, NaN and -0 never win: same bits as the atomic form
+        }
+    }
+    for (; i < e; ++i) {
+      float r[VEC];
+      const int64_t p = __builtin_amdgcn_readfirstlane(a.perm[i]);
+      seg_ld<VEC>(r, a.y + p * a.C + c0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float v = kd_act(kd_affine(r[j], sc[j], sh[j]), a.act);
+        m[j] = v > m[j] ? v : m[j];
+      }
+    }
+    seg_st<VEC>(a.grid + row * a.C + c0, m);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
+  __shared__ float red[4][2][64 * VEC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = lane * VEC;
+  float sc[VEC], sh[VEC], mu[VEC], inv[VEC], s1[VEC], s2[VEC];
+  seg_ld<VEC>(sc, a.sc + c0);
+  seg_ld<VEC>(sh, a.sh + c0);
+  seg_ld<VEC>(mu, a.mean + c0);
+  seg_ld<VEC>(inv, a.invstd + c0);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.ncells; row += nw) {
+    const int s = __builtin_amdgcn_readfirstlane(a.start[row]);
+    const int e = __builtin_amdgcn_readfirstlane(a.start[row + 1]);
+    if (s == e) continue;
+    float mx[VEC], d[VEC];
+    seg_ld<VEC>(mx, a.grid + row * a.C + c0);
+    seg_ld<VEC>(d, a.dout + row * a.C + c0);
+    int cnt[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) cnt[j] = 0;
+    // sweep 1: holders per channel
+    int i = s;
+    for (; i + 4 <= e; i += 4) {
+      float r[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t p = __builtin_amdgcn_readfirstlane(a.perm[i + u]);
+        seg_ld<VEC>(r[u], a.y + p * a.C + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float v = kd_act(kd_affine(r[u][j], sc[j], sh[j]), a.act);
+          cnt[j] += (v > 0.f && v == mx[j]) ? 1 : 0;
+        }
+    }
+    for (; i < e; ++i) {
+      float r[VEC];
+      const int64_t p = __builtin_amdgcn_readfirstlane(a.perm[i]);
+      seg_ld<VEC>(r, a.y + p * a.C + c0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float v = kd_act(kd_affine(r[j], sc[j], sh[j]), a.act);
+        cnt[j] += (v > 0.f && v == mx[j]) ? 1 : 0;
+      }
+    }
+    float share[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) share[j] = d[j] / (float)cnt[j];   // only read where cnt >= 1
+    // sweep 2: the rows come back from L2 (a cell's points were read a few hundred cycles ago)
+    i = s;
+    for (; i + 4 <= e; i += 4) {
+      float r[4][VEC];
+      int64_t p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p[u] = __builtin_amdgcn_readfirstlane(a.perm[i + u]);
+        seg_ld<VEC>(r[u], a.y + p[u] * a.C + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float g[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float v = kd_act(kd_affine(r[u][j], sc[j], sh[j]), a.act);
+          g[j] = (v > 0.f && v == mx[j]) ? share[j] : 0.f;
+          s1[j] += g[j];
+          s2[j] = fmaf(g[j], (r[u][j] - mu[j]) * inv[j], s2[j]);
+        }
+        seg_st<VEC>(a.G + p[u] * a.C + c0, g);
+      }
+    }
+    for (; i < e; ++i) {
+      float r[VEC], g[VEC];
+      const int64_t p = __builtin_amdgcn_readfirstlane(a.perm[i]);
+      seg_ld<VEC>(r, a.y + p * a.C + c0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float v = kd_act(kd_affine(r[j], sc[j], sh[j]), a.act);
+        g[j] = (v > 0.f && v == mx[j]) ? share[j] : 0.f;
+        s1[j] += g[j];
+        s2[j] = fmaf(g[j], (r[j] - mu[j]) * inv[j], s2[j]);
+      }
+      seg_st<VEC>(a.G + p * a.C + c0, g);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { red[wave][0][c0 + j] = s1[j]; red[wave][1][c0 + j] = s2[j]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * a.C; i += 256) {
+    const int st = i / a.C, c = i % a.C;
+    a.partial[((int64_t)blockIdx.x * 2 + st) * a.C + c] = red[0][st][c] + red[1][st][c] + red[2][st][c] + red[3][st][c];
+  }
+}
+
+// rows of G that belong to out-of-range points get no gradient: they are not in any segment
+// (a 256-thread block sweeps 16 * (1024 / C) consecutive points: one wave per handful of stores would be launch-bound)
+__global__ __launch_bounds__(256) void seg_zero_invalid_kernel(const int* __restrict__ row_of_point, float* __restrict__ G,
+                                                               int64_t P, int c4) {
+  const int per = 256 / c4;                      // points per sweep of the block
+  const int q = threadIdx.x % c4, sub = threadIdx.x / c4;
+  const int64_t base = (int64_t)blockIdx.x * per * 16;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int64_t p = base + (int64_t)k * per + sub;
+    if (p < P && row_of_point[p] < 0) kd_st4(G + (p * c4 + q) * 4, kd_zero4());
+  }
+}
+
+inline int seg_grid(int64_t ncells) { const int64_t b = (ncells + 3) / 4; return (int)(b < 4096 ? b : 4096); }
+
+}  // namespace
+
+extern "C" {
+
+size_t kd_lidar_cell_sort_ws_bytes(int B, int64_t N, int H, int W) {
+  const int64_t n = (int64_t)B * H * W + 1;
+  return ((size_t)B * N + (size_t)((n + SCAN_CHUNK - 1) / SCAN_CHUNK)) * sizeof(int);
+}
+
+// Bins the B*N points by BEV grid row.  row_of_point[p] = b*H*W + cell, or -1 for out-of-range points;
+// seg_start[r] .. seg_start[r+1] delimit row r's point ids inside perm (seg_start[B*H*W] = number of in-range points).
+int kd_lidar_cell_sort(const float* pts, int B, int64_t N, int H, int W, float x0, float x1, float y0, float y1,
+                       int* row_of_point, int* seg_start, int* perm, void* ws, size_t ws_bytes, void* stream) {
+  KD_REQUIRE(pts && row_of_point && seg_start && perm && ws && B > 0 && N > 0 && H > 0 && W > 0, KD_ERR_ARG, "kd_lidar_cell_sort: bad args");
+  const int64_t P = (int64_t)B * N, n = (int64_t)B * H * W + 1;
+  KD_REQUIRE(P < (int64_t)INT32_MAX && n < (int64_t)INT32_MAX, KD_ERR_SHAPE, "kd_lidar_cell_sort: more than 2^31 points or cells");
+  KD_REQUIRE(ws_bytes >= kd_lidar_cell_sort_ws_bytes(B, N, H, W), KD_ERR_WORKSPACE, "kd_lidar_cell_sort: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int* rank = (int*)ws;
+  int* bsum = rank + P;
+  const int nb = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  hipError_t e = hipMemsetAsync(seg_start, 0, (size_t)n * sizeof(int), st);
+  KD_REQUIRE(e == hipSuccess, (int)e, "kd_lidar_cell_sort: memset failed: %s", hipGetErrorString(e));
+  const BevGeom g{x0, x1 - x0, y0, y1 - y0, H, W};
+  hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, pts, row_of_point, rank, seg_start, P, N, g);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, st, seg_start, bsum, n);
+  hipLaunchKernelGGL(scan_bsums_kernel, dim3(1), dim3(1024), 0, st, bsum, nb);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, seg_start, bsum, n);
+  hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, row_of_point, rank, seg_start, perm, P);
+  return kd_check_launch("kd_lidar_cell_sort");
+}
+
+// grid[ncells, C] = per-row max of act(y*sc+sh) over the row's points (0 for empty rows); every row is written.
+int kd_lidar_seg_max_fwd(const float* y, const float* sc, const float* sh, int act, const int* seg_start, const int* perm,
+                         float* grid, int64_t ncells, int C, void* stream) {
+  KD_REQUIRE(y && sc && sh && seg_start && perm && grid && ncells > 0, KD_ERR_ARG, "kd_lidar_seg_max_fwd: bad args");
+  KD_REQUIRE(C == 64 || C == 128 || C == 256, KD_ERR_SHAPE, "kd_lidar_seg_max_fwd: C must be 64, 128 or 256 (got %d)", C);
+  KD_REQUIRE(act == KD_ACT_RELU || act == KD_ACT_RELU6, KD_ERR_ARG, "kd_lidar_seg_max_fwd: needs a non-negative activation");
+  SegArgs a{y, sc, sh, act, seg_start, perm, grid, nullptr, nullptr, nullptr, nullptr, nullptr, ncells, C};
+  const dim3 gr(seg_grid(ncells)), bl(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 64) hipLaunchKernelGGL(seg_max_fwd_kernel<1>, gr, bl, 0, st, a);
+  else if (C == 128) hipLaunchKernelGGL(seg_max_fwd_kernel<2>, gr, bl, 0, st, a);
+  else hipLaunchKernelGGL(seg_max_fwd_kernel<4>, gr, bl, 0, st, a);
+  return kd_check_launch("kd_lidar_seg_max_fwd");
+}
+
+int64_t kd_lidar_seg_stat_rows(int64_t ncells) { return seg_grid(ncells); }
+
+// G[P, C] and partial[kd_lidar_seg_stat_rows][2][C]: same contract as kd_lidar_scatter_max_bwd.
+int kd_lidar_seg_max_bwd(const float* y, const float* sc, const float* sh, int act, const float* grid, const float* dout,
+                         const float* mean, const float* invstd, const int* seg_start, const int* perm,
+                         const int* row_of_point, float* G, float* partial, int64_t P, int64_t ncells, int C, void* stream) {
+  KD_REQUIRE(y && sc && sh && grid && dout && mean && invstd && seg_start && perm && row_of_point && G && partial && P > 0 && ncells > 0,
+             KD_ERR_ARG, "kd_lidar_seg_max_bwd: bad args");
+  KD_REQUIRE(C == 64 || C == 128 || C == 256, KD_ERR_SHAPE, "kd_lidar_seg_max_bwd: C must be 64, 128 or 256 (got %d)", C);
+  SegArgs a{y, sc, sh, act, seg_start, perm, const_cast<float*>(grid), dout, mean, invstd, G, partial, ncells, C};
+  const dim3 gr(seg_grid(ncells)), bl(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int c4 = C / 4;
+  const int64_t per_block = (int64_t)(256 / c4) * 16;
+  hipLaunchKernelGGL(seg_zero_invalid_kernel, dim3((unsigned)((P + per_block - 1) / per_block)), dim3(256), 0, st, row_of_point, G, P, c4);
+  if (C == 64) hipLaunchKernelGGL(seg_max_bwd_kernel<1>, gr, bl, 0, st, a);
+  else if (C == 128) hipLaunchKernelGGL(seg_max_bwd_kernel<2>, gr, bl, 0, st, a);
+  else hipLaunchKernelGGL(seg_max_bwd_kernel<4>, gr, bl, 0, st, a);
+  return kd_check_launch("kd_lidar_seg_max_bwd");
+}
+
+}  // extern "C"

@@ -10,6 +10,7 @@ Which reference module each Function stands in for is noted on the Function.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -699,6 +700,11 @@ def run_x4_head(x, units, cls_conv, training):
 
 
 # =================================================================================================
+# training scatter-max: "sorted" (cell-sorted segments, default) or "atomic" (kept for A/B and for widths the
+# segmented kernels do not cover)
+_SCATTER_MODE = os.environ.get("KD_SCATTER", "sorted")
+
+
 class LidarFn(torch.autograd.Function):
     """SpatialLiDAREncoder.forward_vectorized (lidar_encoder.py:57-99): point MLP on all B*N points
     (layer 0 on VALU, layers 1-2 as MFMA GEMMs with M = B*N), BEV binning, scatter-max."""
@@ -745,8 +751,23 @@ class LidarFn(torch.autograd.Function):
         H, W = grid_hw
         C = cur.C
         grid = torch.empty(B * H * W, C, device=pts.device, dtype=torch.float32)
-        lib.call("kd_lidar_scatter_max_fwd", P(pts), P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(grid), B, N, C, H, W,
-                 float(rng[0]), float(rng[1]), float(rng[2]), float(rng[3]), stream())
+        ctx.seg = None
+        if C in (64, 128, 256) and _SCATTER_MODE != "atomic":
+            # bin the point ids by grid row once; forward max and backward tie split then run atomic-free
+            dev = pts.device
+            row_of_point = torch.empty(B * N, device=dev, dtype=torch.int32)
+            seg_start = torch.empty(B * H * W + 1, device=dev, dtype=torch.int32)
+            perm = torch.empty(B * N, device=dev, dtype=torch.int32)
+            nbytes = lib.kd_lidar_cell_sort_ws_bytes(B, N, H, W)
+            ws = ops.workspace(nbytes, dev)
+            lib.call("kd_lidar_cell_sort", P(pts), B, N, H, W, float(rng[0]), float(rng[1]), float(rng[2]), float(rng[3]),
+                     P(row_of_point), P(seg_start), P(perm), P(ws), nbytes, stream())
+            lib.call("kd_lidar_seg_max_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(seg_start), P(perm), P(grid),
+                     B * H * W, C, stream())
+            ctx.seg = (row_of_point, seg_start, perm)
+        else:
+            lib.call("kd_lidar_scatter_max_fwd", P(pts), P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(grid), B, N, C, H, W,
+                     float(rng[0]), float(rng[1]), float(rng[2]), float(rng[3]), stream())
         ctx.recs, ctx.last, ctx.pts, ctx.grid, ctx.shape, ctx.rng = recs, cur, pts, grid, (B, N, C, H, W), rng
         return ops.nchw_from_matrix(grid, (B, H, W))
 
@@ -758,13 +779,20 @@ class LidarFn(torch.autograd.Function):
         dev = dm.device
         Pn = B * N
         G = torch.empty(Pn, C, device=dev, dtype=torch.float32)
-        rows = lib.kd_lidar_scatter_stat_rows(Pn, C)
-        partial = torch.empty(rows * 2 * C, device=dev, dtype=torch.float32)
-        nbytes = lib.kd_lidar_scatter_bwd_ws_bytes(B, H, W, C)
-        ws = ops.workspace(nbytes, dev)
-        lib.call("kd_lidar_scatter_max_bwd", P(pts), P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(ctx.grid), P(dm),
-                 P(cur.bnc.mean), P(cur.bnc.invstd), P(G), P(partial), B, N, C, H, W, float(rng[0]), float(rng[1]),
-                 float(rng[2]), float(rng[3]), P(ws), nbytes, stream())
+        if ctx.seg is not None:
+            row_of_point, seg_start, perm = ctx.seg
+            rows = lib.kd_lidar_seg_stat_rows(B * H * W)
+            partial = torch.empty(rows * 2 * C, device=dev, dtype=torch.float32)
+            lib.call("kd_lidar_seg_max_bwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(ctx.grid), P(dm), P(cur.bnc.mean),
+                     P(cur.bnc.invstd), P(seg_start), P(perm), P(row_of_point), P(G), P(partial), Pn, B * H * W, C, stream())
+        else:
+            rows = lib.kd_lidar_scatter_stat_rows(Pn, C)
+            partial = torch.empty(rows * 2 * C, device=dev, dtype=torch.float32)
+            nbytes = lib.kd_lidar_scatter_bwd_ws_bytes(B, H, W, C)
+            ws = ops.workspace(nbytes, dev)
+            lib.call("kd_lidar_scatter_max_bwd", P(pts), P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(ctx.grid), P(dm),
+                     P(cur.bnc.mean), P(cur.bnc.invstd), P(G), P(partial), B, N, C, H, W, float(rng[0]), float(rng[1]),
+                     float(rng[2]), float(rng[3]), P(ws), nbytes, stream())
         grads, _ = chain_backward(ctx.recs, ("G", G, partial, rows), need_input_grad=False)
         return (None, None, None, None, None, *grads)
 

@@ -1,0 +1,145 @@
+"""Cell-sorted (segmented) scatter-max against the atomic scatter-max entry points, through the C ABI.
+Both implement lidar_encoder.py:57-99 (BEV binning + amax + the even tie split of its backward); the
+atomic pair is already pinned to the oracle and the golden vectors (test_gpu_parity.py / test_gpu_units.py),
+so here the two are compared with each other BIT FOR BIT on inputs built to hit the awkward cases:
+exact ties (duplicated points), empty cells, out-of-range and NaN points, a padded tail that lands
+thousands of points in one cell, every supported width."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu]
+
+RNG = (-50.0, 50.0, -50.0, 50.0)
+
+
+def _P(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _inputs(B, N, C, seed, pad=0, dup=0, nan=0):
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.randn(B, N, 4, generator=g) * torch.tensor([40.0, 40.0, 2.0, 1.0])
+    if pad:
+        pts[:, N - pad:] = 0.0                       # zero padding: all in the cell that holds (0, 0)
+    y = torch.randn(B * N, C, generator=g)
+    if dup:
+        src = torch.randint(0, N - pad - dup, (dup,), generator=g)
+        pts[:, N - pad - dup:N - pad] = pts[:, src]  # same cell ...
+        yv = y.view(B, N, C)
+        yv[:, N - pad - dup:N - pad] = yv[:, src]    # ... and same features: exact ties on every channel
+    if nan:
+        pts[:, :nan, 0] = float("nan")
+        pts[:, nan:2 * nan, 1] = float("inf")
+    sc = torch.rand(C, generator=g) + 0.5
+    sh = torch.randn(C, generator=g) * 0.2
+    mean = torch.randn(C, generator=g) * 0.1
+    invstd = torch.rand(C, generator=g) + 0.5
+    return [t.cuda().contiguous() for t in (pts.view(B * N, 4), y, sc, sh, mean, invstd)]
+
+
+def _sort(lib, pts, B, N, H, W):
+    dev = pts.device
+    row = torch.empty(B * N, device=dev, dtype=torch.int32)
+    start = torch.empty(B * H * W + 1, device=dev, dtype=torch.int32)
+    perm = torch.full((B * N,), -7, device=dev, dtype=torch.int32)
+    nb = lib.kd_lidar_cell_sort_ws_bytes(B, N, H, W)
+    ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+    lib.call("kd_lidar_cell_sort", _P(pts), B, N, H, W, *RNG, _P(row), _P(start), _P(perm), _P(ws), nb, None)
+    return row, start, perm
+
+
+@pytest.mark.parametrize("B,N,H,W,pad,nan", [(1, 257, 4, 4, 0, 0), (3, 5000, 16, 16, 700, 40), (2, 9000, 64, 64, 0, 13),
+                                             (2, 40, 32, 32, 0, 0), (5, 3001, 33, 17, 100, 5)])
+def test_cell_sort_groups_the_in_range_points_by_row(B, N, H, W, pad, nan):
+    from kdrt.lib import lib
+    pts = _inputs(B, N, 64, 3, pad=pad, nan=nan)[0]
+    row, start, perm = _sort(lib, pts, B, N, H, W)
+    cell = torch.empty(B * N, device="cuda", dtype=torch.int32)
+    lib.call("kd_lidar_bev_index", _P(pts), _P(cell), B * N, H, W, *RNG, None)
+    torch.cuda.synchronize()
+    cell, row, start, perm = cell.cpu().numpy(), row.cpu().numpy(), start.cpu().numpy(), perm.cpu().numpy()
+    want_row = np.where(cell >= 0, (np.arange(B * N) // N) * (H * W) + cell, -1)
+    assert np.array_equal(row, want_row)
+    counts = np.bincount(want_row[want_row >= 0], minlength=B * H * W)
+    assert start[0] == 0 and np.array_equal(np.diff(start), counts)
+    nv = int(start[-1])
+    assert nv == int((want_row >= 0).sum())
+    used = perm[:nv]
+    assert np.array_equal(np.sort(used), np.nonzero(want_row >= 0)[0])          # a permutation of the in-range ids
+    assert np.array_equal(want_row[used], np.repeat(np.arange(B * H * W), counts))   # grouped by row, rows ascending
+    assert np.all(perm[nv:] == -7)                                              # nothing written past the end
+
+
+@pytest.mark.parametrize("C", (64, 128, 256))
+@pytest.mark.parametrize("B,N,H,W,pad,dup,nan", [(2, 3000, 16, 16, 300, 200, 20), (1, 500, 64, 64, 0, 50, 0),
+                                                 (3, 20000, 64, 64, 2500, 1000, 7)])
+def test_segmented_scatter_matches_atomic_scatter_bitwise(C, B, N, H, W, pad, dup, nan):
+    from kdrt.lib import lib
+    pts, y, sc, sh, mean, invstd = _inputs(B, N, C, 11 + C, pad=pad, dup=dup, nan=nan)
+    ncells = B * H * W
+    act = 1
+    # atomic pair
+    grid_a = torch.empty(ncells, C, device="cuda")
+    lib.call("kd_lidar_scatter_max_fwd", _P(pts), _P(y), _P(sc), _P(sh), act, _P(grid_a), B, N, C, H, W, *RNG, None)
+    dout = torch.randn(ncells, C, generator=torch.Generator().manual_seed(5)).cuda()
+    G_a = torch.full((B * N, C), 3.0, device="cuda")
+    rows_a = lib.kd_lidar_scatter_stat_rows(B * N, C)
+    part_a = torch.empty(rows_a, 2, C, device="cuda")
+    nb = lib.kd_lidar_scatter_bwd_ws_bytes(B, H, W, C)
+    ws = torch.empty(nb, device="cuda", dtype=torch.uint8)
+    lib.call("kd_lidar_scatter_max_bwd", _P(pts), _P(y), _P(sc), _P(sh), act, _P(grid_a), _P(dout), _P(mean), _P(invstd),
+             _P(G_a), _P(part_a), B, N, C, H, W, *RNG, _P(ws), nb, None)
+    # segmented pair
+    row, start, perm = _sort(lib, pts, B, N, H, W)
+    grid_s = torch.full((ncells, C), -1.0, device="cuda")          # every row must be overwritten, empty ones with 0
+    lib.call("kd_lidar_seg_max_fwd", _P(y), _P(sc), _P(sh), act, _P(start), _P(perm), _P(grid_s), ncells, C, None)
+    G_s = torch.full((B * N, C), 3.0, device="cuda")
+    rows_s = lib.kd_lidar_seg_stat_rows(ncells)
+    part_s = torch.empty(rows_s, 2, C, device="cuda")
+    lib.call("kd_lidar_seg_max_bwd", _P(y), _P(sc), _P(sh), act, _P(grid_s), _P(dout), _P(mean), _P(invstd), _P(start), _P(perm),
+             _P(row), _P(G_s), _P(part_s), B * N, ncells, C, None)
+    torch.cuda.synchronize()
+    assert torch.equal(grid_a.view(torch.int32), grid_s.view(torch.int32))
+    assert torch.equal(G_a.view(torch.int32), G_s.view(torch.int32))
+    # ties really happened, and were split
+    holders = (G_s != 0).sum().item()
+    occupied = ((grid_s > 0) & (dout != 0)).sum().item()
+    assert holders >= occupied > 0 and (dup == 0 or holders > occupied)
+    sa, ss = part_a.double().sum(0), part_s.double().sum(0)
+    assert torch.allclose(sa, ss, rtol=1e-5, atol=1e-5 * float(sa.abs().max()))
+    # the stats are what they claim to be
+    xhat = (y.double() - mean.double()) * invstd.double()
+    want = torch.stack([G_s.double().sum(0), (G_s.double() * xhat).sum(0)])
+    assert torch.allclose(ss, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+
+
+def test_segmented_scatter_is_run_to_run_deterministic():
+    from kdrt.lib import lib
+    B, N, H, W, C = 2, 20000, 64, 64, 128
+    pts, y, sc, sh, mean, invstd = _inputs(B, N, C, 77, pad=1000, dup=500)
+    dout = torch.randn(B * H * W, C, generator=torch.Generator().manual_seed(6)).cuda()
+    outs = []
+    for _ in range(3):
+        row, start, perm = _sort(lib, pts, B, N, H, W)
+        grid = torch.empty(B * H * W, C, device="cuda")
+        lib.call("kd_lidar_seg_max_fwd", _P(y), _P(sc), _P(sh), 1, _P(start), _P(perm), _P(grid), B * H * W, C, None)
+        G = torch.empty(B * N, C, device="cuda")
+        part = torch.empty(lib.kd_lidar_seg_stat_rows(B * H * W), 2, C, device="cuda")
+        lib.call("kd_lidar_seg_max_bwd", _P(y), _P(sc), _P(sh), 1, _P(grid), _P(dout), _P(mean), _P(invstd), _P(start), _P(perm),
+                 _P(row), _P(G), _P(part), B * N, B * H * W, C, None)
+        torch.cuda.synchronize()
+        outs.append((grid.clone(), G.clone(), part.clone()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_segmented_scatter_rejects_unsupported_width():
+    from kdrt.lib import KDError, lib
+    t = torch.zeros(64, device="cuda")
+    i = torch.zeros(64, device="cuda", dtype=torch.int32)
+    with pytest.raises(KDError, match="C must be 64, 128 or 256"):
+        lib.call("kd_lidar_seg_max_fwd", _P(t), _P(t), _P(t), 1, _P(i), _P(i), _P(t), 1, 96, None)
