@@ -151,6 +151,8 @@ int kd_lidar_bev_index(const float* pts, int* cell, int64_t P, int H, int W, flo
 size_t kd_lidar_cell_sort_ws_bytes(int B, int64_t N, int H, int W);
 int kd_lidar_cell_sort(const float* pts, int B, int64_t N, int H, int W, float x0, float x1, float y0, float y1,
                        int* row_of_point, int* seg_start, int* perm, void* ws, size_t ws_bytes, void* stream);
+int kd_lidar_gather_sorted(const float* pts, const int* perm, const int* row_of_point, const int* nvalid_dev,
+                           float* out_pts, int* out_row, int64_t P, void* stream);
 int kd_lidar_seg_max_fwd(const float* y, const float* sc, const float* sh, int act, const int* seg_start,
                          const int* perm, float* grid, int64_t ncells, int C, void* stream);
 int64_t kd_lidar_seg_stat_rows(int64_t ncells);

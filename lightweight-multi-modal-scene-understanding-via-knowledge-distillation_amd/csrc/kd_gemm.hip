@@ -349,8 +349,12 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2) ? 3 : 2) : ((PR
       int cell[NP];
       unsigned cur[NP][NJ];
 #pragma unroll
+      // Each thread owns NP CONSECUTIVE rows (inside one 32-row run of the half): when the caller hands the points
+      // over sorted by cell (kd_lidar_cell_sort + kd_lidar_gather_sorted) neighbouring rows share a cell, the running
+      // maximum is carried in registers and only the last row of a run touches the grid -- ~5x fewer atomics.
+      // Unsorted input is still correct: every row is then its own run.
       for (int i = 0; i < NP; ++i) {
-        const int rr = r8 + 8 * i;
+        const int rr = r8 * NP + i;
         int64_t row = m0 + (rr >> 5) * 64 + h * 32 + (rr & 31);
         const bool rok = row < g.M;
         row = rok ? row : (int64_t)g.M - 1;
@@ -360,15 +364,21 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2) ? 3 : 2) : ((PR
 #pragma unroll
         for (int j = 0; j < NJ; ++j) cur[i][j] = src[ok4[j] ? 32 * j : 0];
       }
+      float run[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) run[j] = 0.f;
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
-        const int rr = r8 + 8 * i;
+        const int rr = r8 * NP + i;
         unsigned* dst = grid + (int64_t)(cell[i] < 0 ? 0 : cell[i]) * g.ldc + cb4;
+        const bool first = i == 0 || cell[i] != cell[i > 0 ? i - 1 : 0];
+        const bool last = i == NP - 1 || cell[i] != cell[i < NP - 1 ? i + 1 : i];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const float v = kd_act(kd_affine(T4[rr * TLD4 + l32 + 32 * j] + b4[j], s4[j], h4[j]), g.epi_act);
-          const unsigned u = __float_as_uint(v);
-          if (cell[i] >= 0 && ok4[j] && v > 0.f && u > cur[i][j]) atomicMax(dst + 32 * j, u);
+          run[j] = (first || v > run[j]) ? v : run[j];
+          const unsigned u = __float_as_uint(run[j]);
+          if (last && cell[i] >= 0 && ok4[j] && run[j] > 0.f && u > cur[i][j]) atomicMax(dst + 32 * j, u);
         }
       }
     }

@@ -671,6 +671,16 @@ __global__ __launch_bounds__(256) void seg_zero_invalid_kernel(const int* __rest
   }
 }
 
+// the in-range points in cell order, with their grid rows: the eval path's point list (see kd_lidar_compact)
+__global__ void seg_gather_kernel(const float* __restrict__ pts, const int* __restrict__ perm, const int* __restrict__ row_of_point,
+                                  const int* __restrict__ nvalid, float* __restrict__ out_pts, int* __restrict__ out_row, int64_t P) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P || i >= *nvalid) return;
+  const int p = perm[i];
+  kd_st4(out_pts + i * 4, kd_ld4(pts + (int64_t)p * 4));
+  out_row[i] = row_of_point[p];
+}
+
 inline int seg_grid(int64_t ncells) { const int64_t b = (ncells + 3) / 4; return (int)(b < 4096 ? b : 4096); }
 
 }  // namespace
@@ -703,6 +713,17 @@ int kd_lidar_cell_sort(const float* pts, int B, int64_t N, int H, int W, float x
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, seg_start, bsum, n);
   hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, row_of_point, rank, seg_start, perm, P);
   return kd_check_launch("kd_lidar_cell_sort");
+}
+
+// out_pts[i] = pts[perm[i]], out_row[i] = row_of_point[perm[i]] for i < *nvalid_dev (= seg_start[B*H*W]): the same
+// contract as kd_lidar_compact's outputs, but ordered by grid row, which lets kd_lidar_l2_fwd_scatter merge
+// neighbouring rows before it touches the grid.
+int kd_lidar_gather_sorted(const float* pts, const int* perm, const int* row_of_point, const int* nvalid_dev, float* out_pts,
+                           int* out_row, int64_t P, void* stream) {
+  KD_REQUIRE(pts && perm && row_of_point && nvalid_dev && out_pts && out_row && P > 0, KD_ERR_ARG, "kd_lidar_gather_sorted: bad args");
+  hipLaunchKernelGGL(seg_gather_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts, perm, row_of_point,
+                     nvalid_dev, out_pts, out_row, P);
+  return kd_check_launch("kd_lidar_gather_sorted");
 }
 
 // grid[ncells, C] = per-row max of act(y*sc+sh) over the row's points (0 for empty rows); every row is written.

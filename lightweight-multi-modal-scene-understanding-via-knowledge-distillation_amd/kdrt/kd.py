@@ -10,7 +10,7 @@ from typing import Optional
 
 import torch
 
-from . import gradsink
+from . import gradsink, units
 from .ddp import BucketedAllReduce
 from .losses import kd_objective
 from .optim import FusedAdamW
@@ -29,6 +29,7 @@ class KDStep:
             p.requires_grad_(False)
 
     def __call__(self, images, points, labels):
+        units.clear_step_caches()          # the teacher/student share of the point bins never outlives one step
         with torch.no_grad():
             zt, mt = self.teacher(images, points, return_intermediates=True)
         gradsink.active = self.sink

@@ -705,6 +705,35 @@ def run_x4_head(x, units, cls_conv, training):
 _SCATTER_MODE = os.environ.get("KD_SCATTER", "sorted")
 
 
+_sort_cache: dict = {}
+
+
+def clear_step_caches():
+    """Called by kdrt.kd at the start of every KD step: nothing computed for one step may serve the next."""
+    _sort_cache.clear()
+
+
+def cell_sort(pts, B, N, H, W, rng):
+    """Point ids binned by BEV grid row (kd_lidar_cell_sort) -> (row_of_point, seg_start, perm).  The frozen teacher and
+    the student of ONE KD step see the same point tensor, so the second caller reuses the first one's bins; the entry
+    keeps the tensor alive (its address cannot be recycled) and is dropped on any in-place write or at the next step."""
+    key = (pts.data_ptr(), pts._version, B, N, H, W, tuple(float(r) for r in rng), stream())
+    hit = _sort_cache.get("entry")
+    if hit is not None and hit[0] == key:
+        return hit[2]
+    dev = pts.device
+    row_of_point = torch.empty(B * N, device=dev, dtype=torch.int32)
+    seg_start = torch.empty(B * H * W + 1, device=dev, dtype=torch.int32)
+    perm = torch.empty(B * N, device=dev, dtype=torch.int32)
+    nbytes = lib.kd_lidar_cell_sort_ws_bytes(B, N, H, W)
+    ws = ops.workspace(nbytes, dev)
+    lib.call("kd_lidar_cell_sort", P(pts), B, N, H, W, float(rng[0]), float(rng[1]), float(rng[2]), float(rng[3]),
+             P(row_of_point), P(seg_start), P(perm), P(ws), nbytes, stream())
+    out = (row_of_point, seg_start, perm)
+    _sort_cache["entry"] = (key, pts, out)
+    return out
+
+
 class LidarFn(torch.autograd.Function):
     """SpatialLiDAREncoder.forward_vectorized (lidar_encoder.py:57-99): point MLP on all B*N points
     (layer 0 on VALU, layers 1-2 as MFMA GEMMs with M = B*N), BEV binning, scatter-max."""
@@ -723,9 +752,16 @@ class LidarFn(torch.autograd.Function):
             dev = pts.device
             cpts = torch.empty(B * N, 4, device=dev, dtype=torch.float32)
             ccell = torch.empty(B * N, device=dev, dtype=torch.int32)
-            counter = torch.empty(1, device=dev, dtype=torch.int32)
-            lib.call("kd_lidar_compact", P(pts), P(cpts), P(ccell), P(counter), B, N, H, W, float(rng[0]), float(rng[1]),
-                     float(rng[2]), float(rng[3]), stream())
+            if _SCATTER_MODE != "atomic":
+                # in-range points in CELL order (bins shared with the student's training scatter of the same step):
+                # the fused scatter epilogue then merges neighbouring rows in registers before touching the grid
+                row_of_point, seg_start, perm = cell_sort(pts, B, N, H, W, rng)
+                counter = seg_start[B * H * W:]
+                lib.call("kd_lidar_gather_sorted", P(pts), P(perm), P(row_of_point), P(counter), P(cpts), P(ccell), B * N, stream())
+            else:
+                counter = torch.empty(1, device=dev, dtype=torch.int32)
+                lib.call("kd_lidar_compact", P(pts), P(cpts), P(ccell), P(counter), B, N, H, W, float(rng[0]), float(rng[1]),
+                         float(rng[2]), float(rng[3]), stream())
             # the row count stays on the device: the kernels read it themselves (no host sync, the CPU keeps
             # running a whole step ahead of the GPU)
             last = units[-1]
@@ -754,14 +790,7 @@ class LidarFn(torch.autograd.Function):
         ctx.seg = None
         if C in (64, 128, 256) and _SCATTER_MODE != "atomic":
             # bin the point ids by grid row once; forward max and backward tie split then run atomic-free
-            dev = pts.device
-            row_of_point = torch.empty(B * N, device=dev, dtype=torch.int32)
-            seg_start = torch.empty(B * H * W + 1, device=dev, dtype=torch.int32)
-            perm = torch.empty(B * N, device=dev, dtype=torch.int32)
-            nbytes = lib.kd_lidar_cell_sort_ws_bytes(B, N, H, W)
-            ws = ops.workspace(nbytes, dev)
-            lib.call("kd_lidar_cell_sort", P(pts), B, N, H, W, float(rng[0]), float(rng[1]), float(rng[2]), float(rng[3]),
-                     P(row_of_point), P(seg_start), P(perm), P(ws), nbytes, stream())
+            row_of_point, seg_start, perm = cell_sort(pts, B, N, H, W, rng)
             lib.call("kd_lidar_seg_max_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(seg_start), P(perm), P(grid),
                      B * H * W, C, stream())
             ctx.seg = (row_of_point, seg_start, perm)

@@ -143,3 +143,53 @@ def test_segmented_scatter_rejects_unsupported_width():
     i = torch.zeros(64, device="cuda", dtype=torch.int32)
     with pytest.raises(KDError, match="C must be 64, 128 or 256"):
         lib.call("kd_lidar_seg_max_fwd", _P(t), _P(t), _P(t), 1, _P(i), _P(i), _P(t), 1, 96, None)
+
+
+def test_gather_sorted_lists_the_in_range_points_in_cell_order():
+    from kdrt.lib import lib
+    B, N, H, W = 3, 7000, 32, 32
+    pts = _inputs(B, N, 64, 9, pad=300, nan=11)[0]
+    row, start, perm = _sort(lib, pts, B, N, H, W)
+    out_pts = torch.full((B * N, 4), -5.0, device="cuda")
+    out_row = torch.full((B * N,), -9, device="cuda", dtype=torch.int32)
+    lib.call("kd_lidar_gather_sorted", _P(pts), _P(perm), _P(row), _P(start[B * H * W:]), _P(out_pts), _P(out_row), B * N, None)
+    torch.cuda.synchronize()
+    nv = int(start[-1])
+    assert 0 < nv < B * N
+    idx = perm[:nv].long()
+    assert torch.equal(out_pts[:nv], pts[idx]) and torch.equal(out_row[:nv], row[idx])
+    assert bool((out_row[:nv][1:] >= out_row[:nv][:-1]).all())
+    assert bool((out_pts[nv:] == -5.0).all()) and bool((out_row[nv:] == -9).all())
+
+
+@pytest.mark.parametrize("training", (False, True))
+def test_lidar_encoder_same_bits_with_sorted_and_atomic_scatter(training):
+    """The whole encoder (eval: compaction + fused scatter epilogue; train: forward AND parameter gradients)."""
+    from kdrt import units
+    from src.models.lidar_encoder import LiDAREncoder
+    torch.manual_seed(3)
+    enc = LiDAREncoder(encoder_type="spatial", grid_size=(32, 32)).cuda().train(training)
+    # (NaN / Inf coordinates only in eval: in train mode they poison the batch statistics, in the reference too)
+    pts = _inputs(2, 6000, 64, 21, pad=500, dup=300, nan=0 if training else 9)[0].view(2, 6000, 4)
+    res = {}
+    saved = units._SCATTER_MODE
+    try:
+        for mode in ("atomic", "sorted"):
+            units._SCATTER_MODE = mode
+            units.clear_step_caches()
+            enc.zero_grad()
+            if training:
+                y = enc(pts)
+                (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+                # (conv biases in front of a BatchNorm have a zero true gradient: rounding noise, not compared)
+                res[mode] = (y.detach().clone(), [p.grad.clone() for n, p in enc.named_parameters()
+                                                  if not n.endswith(("point_mlp.0.bias", "point_mlp.3.bias", "point_mlp.6.bias"))])
+            else:
+                with torch.no_grad():
+                    res[mode] = (enc(pts).clone(), [])
+    finally:
+        units._SCATTER_MODE = saved
+    assert torch.equal(res["atomic"][0].view(torch.int32), res["sorted"][0].view(torch.int32))
+    for a, b in zip(res["atomic"][1], res["sorted"][1]):
+        assert bool(torch.isfinite(a).all())
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(a.abs().max()))
