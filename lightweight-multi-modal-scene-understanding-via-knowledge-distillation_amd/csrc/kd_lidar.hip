@@ -491,6 +491,93 @@ __global__ void seg_fill_kernel(const int* __restrict__ row_of_point, const int*
   if (row >= 0) perm[start[row] + rank[p]] = (int)p;
 }
 
+// ---- stable sort of the POINTS by (frame, cell) ---------------------------------------------------
+// Same bins as above but with a DETERMINISTIC in-cell order (ascending point id), so the point MLP itself can run on
+// the sorted points: every cell's rows are then one contiguous range (the segmented kernels stream instead of
+// gathering 512-byte rows), the out-of-range points are one contiguous tail, and the eval path's compacted point
+// list is simply the head of the same array.  Order-dependent sums (BatchNorm statistics, weight gradients) see a
+// fixed order, so training stays bitwise run-to-run deterministic -- the atomic rank above cannot offer that.
+// Counting sort, three passes: (A) 1024-point blocks: in-wave rank by key comparison across lanes, the 16 waves
+// take turns on an LDS histogram (block-local stable rank), the histogram goes to T[frame][block][key];
+// (B) per (frame, key) exclusive prefix over the blocks + totals, global scan of the totals (-> seg_start);
+// (C) scatter: position = seg_start[key] + T[frame][block][key] + block-local rank.
+constexpr int SORT_BLK = 1024;
+constexpr int SORT_MAX_BINS = 12288;          // H*W + 1 ints of LDS
+
+__global__ __launch_bounds__(SORT_BLK) void stable_count_kernel(const float* __restrict__ pts, int* __restrict__ key_out,
+                                                                int* __restrict__ lrank_out, int* __restrict__ T, int64_t N,
+                                                                int nblk, BevGeom g) {
+  extern __shared__ int hist[];
+  const int HW = g.H * g.W, nb = HW + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  for (int i = tid; i < nb; i += SORT_BLK) hist[i] = 0;
+  const int64_t n = (int64_t)blk * SORT_BLK + tid;
+  const bool act = n < N;
+  const int64_t p = (int64_t)b * N + (act ? n : 0);
+  int key = -1;
+  if (act) {
+    int c;
+    key = bev_cell(kd_ld4(pts + p * 4), g, c) ? c : HW;
+  }
+  int r = 0, cnt = 0;                            // lower lanes / all lanes of this wave with the same key
+#pragma unroll 16
+  for (int j = 0; j < 64; ++j) {
+    const int kj = __shfl(key, j);
+    cnt += kj == key ? 1 : 0;
+    r += (kj == key && j < lane) ? 1 : 0;
+  }
+  __syncthreads();
+  int lr = 0;
+  for (int w = 0; w < SORT_BLK / 64; ++w) {
+    if (wave == w && act) lr = hist[key] + r;
+    __syncthreads();
+    if (wave == w && act && r == cnt - 1) hist[key] += cnt;      // the last lane of each key group
+    __syncthreads();
+  }
+  if (act) { key_out[p] = key; lrank_out[p] = lr; }
+  int* Tb = T + ((int64_t)b * nblk + blk) * nb;
+  for (int i = tid; i < nb; i += SORT_BLK) Tb[i] = hist[i];
+}
+
+// T[b][blk][key] <- exclusive prefix over blk; totals to counts[b*HW + key] (in range) / inv[b] (key == HW)
+__global__ void stable_prefix_kernel(int* T, int* __restrict__ counts, int* __restrict__ inv, int B, int nblk, int HW) {
+  const int nb = HW + 1;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx == 0) counts[(int64_t)B * HW] = 0;
+  if (idx >= (int64_t)B * nb) return;
+  const int b = (int)(idx / nb), key = (int)(idx % nb);
+  int run = 0;
+  for (int blk = 0; blk < nblk; ++blk) {
+    int* t = T + ((int64_t)b * nblk + blk) * nb + key;
+    const int v = *t;
+    *t = run;
+    run += v;
+  }
+  if (key < HW) counts[(int64_t)b * HW + key] = run; else inv[b] = run;
+}
+
+// inv[b] <- first position of frame b's out-of-range points (they follow all in-range points, frame by frame)
+__global__ void stable_inv_base_kernel(const int* __restrict__ seg_start, int* inv, int B, int64_t ncells) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int run = seg_start[ncells];
+  for (int b = 0; b < B; ++b) { const int v = inv[b]; inv[b] = run; run += v; }
+}
+
+__global__ void stable_fill_kernel(const float* __restrict__ pts, const int* __restrict__ key, const int* __restrict__ lrank,
+                                   const int* __restrict__ T, const int* __restrict__ seg_start, const int* __restrict__ inv_base,
+                                   float* __restrict__ pts_sorted, int* __restrict__ row_sorted, int* __restrict__ perm,
+                                   int64_t P, int64_t N, int nblk, int HW) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int b = (int)(p / N), blk = (int)((p % N) / SORT_BLK), k = key[p];
+  const int base = k < HW ? seg_start[(int64_t)b * HW + k] : inv_base[b];
+  const int64_t pos = (int64_t)base + T[((int64_t)b * nblk + blk) * (HW + 1) + k] + lrank[p];
+  kd_st4(pts_sorted + pos * 4, kd_ld4(pts + p * 4));
+  row_sorted[pos] = k < HW ? b * HW + k : -1;
+  if (perm) perm[pos] = (int)p;
+}
+
 struct SegArgs {
   const float* y; const float* sc; const float* sh; int act;          // deferred [P, C]
   const int* start; const int* perm;                                  // [ncells + 1], [P]
@@ -533,7 +620,7 @@ __global__ __launch_bounds__(256) void seg_max_fwd_kernel(SegArgs a) {
       float r[4][VEC];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int64_t p = __builtin_amdgcn_readfirstlane(a.perm[i + u]);
+        const int64_t p = (a.perm ? __builtin_amdgcn_readfirstlane(a.perm[i + u]) : i + u);
         seg_ld<VEC>(r[u], a.y + p * a.C + c0);
       }
 #pragma unroll
@@ -546,7 +633,7 @@ __global__ __launch_bounds__(256) void seg_max_fwd_kernel(SegArgs a) {
     }
     for (; i < e; ++i) {
       float r[VEC];
-      const int64_t p = __builtin_amdgcn_readfirstlane(a.perm[i]);
+      const int64_t p = (a.perm ? __builtin_amdgcn_readfirstlane(a.perm[i]) : i);
       seg_ld<VEC>(r, a.y + p * a.C + c0);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -587,7 +674,7 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
       float r[4][VEC];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int64_t p = __builtin_amdgcn_readfirstlane(a.perm[i + u]);
+        const int64_t p = (a.perm ? __builtin_amdgcn_readfirstlane(a.perm[i + u]) : i + u);
         seg_ld<VEC>(r[u], a.y + p * a.C + c0);
       }
 #pragma unroll
@@ -600,7 +687,7 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
     }
     for (; i < e; ++i) {
       float r[VEC];
-      const int64_t p = __builtin_amdgcn_readfirstlane(a.perm[i]);
+      const int64_t p = (a.perm ? __builtin_amdgcn_readfirstlane(a.perm[i]) : i);
       seg_ld<VEC>(r, a.y + p * a.C + c0);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -618,7 +705,7 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
       int64_t p[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        p[u] = __builtin_amdgcn_readfirstlane(a.perm[i + u]);
+        p[u] = (a.perm ? __builtin_amdgcn_readfirstlane(a.perm[i + u]) : i + u);
         seg_ld<VEC>(r[u], a.y + p[u] * a.C + c0);
       }
 #pragma unroll
@@ -636,7 +723,7 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
     }
     for (; i < e; ++i) {
       float r[VEC], g[VEC];
-      const int64_t p = __builtin_amdgcn_readfirstlane(a.perm[i]);
+      const int64_t p = (a.perm ? __builtin_amdgcn_readfirstlane(a.perm[i]) : i);
       seg_ld<VEC>(r, a.y + p * a.C + c0);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -715,6 +802,47 @@ int kd_lidar_cell_sort(const float* pts, int B, int64_t N, int H, int W, float x
   return kd_check_launch("kd_lidar_cell_sort");
 }
 
+size_t kd_lidar_sort_points_ws_bytes(int B, int64_t N, int H, int W) {
+  const int64_t P = (int64_t)B * N, nblk = (N + SORT_BLK - 1) / SORT_BLK, nb = (int64_t)H * W + 1, n = (int64_t)B * H * W + 1;
+  return (size_t)(2 * P + (int64_t)B * nblk * nb + B + (n + SCAN_CHUNK - 1) / SCAN_CHUNK) * sizeof(int);
+}
+
+// Stable sort of the points by (frame, cell); out-of-range points go to the end (frame by frame, original order).
+//   pts_sorted[B*N, 4]; row_sorted[B*N] = grid row of each sorted point or -1; seg_start[B*H*W + 1] as in
+//   kd_lidar_cell_sort (seg_start[B*H*W] = number of in-range points); perm (optional, may be NULL): sorted -> original id.
+// Returns KD_ERR_SHAPE when H*W + 1 exceeds the LDS histogram (callers fall back to kd_lidar_cell_sort).
+int kd_lidar_sort_points(const float* pts, int B, int64_t N, int H, int W, float x0, float x1, float y0, float y1,
+                         float* pts_sorted, int* row_sorted, int* seg_start, int* perm, void* ws, size_t ws_bytes,
+                         void* stream) {
+  KD_REQUIRE(pts && pts_sorted && row_sorted && seg_start && ws && B > 0 && N > 0 && H > 0 && W > 0, KD_ERR_ARG, "kd_lidar_sort_points: bad args");
+  const int64_t P = (int64_t)B * N, ncells = (int64_t)B * H * W, n = ncells + 1;
+  const int HW = H * W, nb = HW + 1;
+  KD_REQUIRE(nb <= SORT_MAX_BINS, KD_ERR_SHAPE, "kd_lidar_sort_points: H*W + 1 = %d bins exceed %d", nb, SORT_MAX_BINS);
+  KD_REQUIRE(P < (int64_t)INT32_MAX && n < (int64_t)INT32_MAX, KD_ERR_SHAPE, "kd_lidar_sort_points: more than 2^31 points or cells");
+  KD_REQUIRE(ws_bytes >= kd_lidar_sort_points_ws_bytes(B, N, H, W), KD_ERR_WORKSPACE, "kd_lidar_sort_points: workspace too small");
+  const int nblk = (int)((N + SORT_BLK - 1) / SORT_BLK);
+  KD_REQUIRE((int64_t)B * nblk < (int64_t)INT32_MAX, KD_ERR_SHAPE, "kd_lidar_sort_points: too many blocks");
+  hipStream_t st = (hipStream_t)stream;
+  int* key = (int*)ws;
+  int* lrank = key + P;
+  int* T = lrank + P;
+  int* inv = T + (int64_t)B * nblk * nb;
+  int* bsum = inv + B;
+  const int nsb = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  const BevGeom g{x0, x1 - x0, y0, y1 - y0, H, W};
+  hipLaunchKernelGGL(stable_count_kernel, dim3((unsigned)(B * nblk)), dim3(SORT_BLK), (size_t)nb * sizeof(int), st, pts, key, lrank, T,
+                     N, nblk, g);
+  const int64_t nbk = (int64_t)B * nb;
+  hipLaunchKernelGGL(stable_prefix_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, T, seg_start, inv, B, nblk, HW);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(256), 0, st, seg_start, bsum, n);
+  hipLaunchKernelGGL(scan_bsums_kernel, dim3(1), dim3(1024), 0, st, bsum, nsb);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(256), 0, st, seg_start, bsum, n);
+  hipLaunchKernelGGL(stable_inv_base_kernel, dim3(1), dim3(64), 0, st, seg_start, inv, B, ncells);
+  hipLaunchKernelGGL(stable_fill_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, pts, key, lrank, T, seg_start, inv,
+                     pts_sorted, row_sorted, perm, P, N, nblk, HW);
+  return kd_check_launch("kd_lidar_sort_points");
+}
+
 // out_pts[i] = pts[perm[i]], out_row[i] = row_of_point[perm[i]] for i < *nvalid_dev (= seg_start[B*H*W]): the same
 // contract as kd_lidar_compact's outputs, but ordered by grid row, which lets kd_lidar_l2_fwd_scatter merge
 // neighbouring rows before it touches the grid.
@@ -729,7 +857,7 @@ int kd_lidar_gather_sorted(const float* pts, const int* perm, const int* row_of_
 // grid[ncells, C] = per-row max of act(y*sc+sh) over the row's points (0 for empty rows); every row is written.
 int kd_lidar_seg_max_fwd(const float* y, const float* sc, const float* sh, int act, const int* seg_start, const int* perm,
                          float* grid, int64_t ncells, int C, void* stream) {
-  KD_REQUIRE(y && sc && sh && seg_start && perm && grid && ncells > 0, KD_ERR_ARG, "kd_lidar_seg_max_fwd: bad args");
+  KD_REQUIRE(y && sc && sh && seg_start && grid && ncells > 0, KD_ERR_ARG, "kd_lidar_seg_max_fwd: bad args");
   KD_REQUIRE(C == 64 || C == 128 || C == 256, KD_ERR_SHAPE, "kd_lidar_seg_max_fwd: C must be 64, 128 or 256 (got %d)", C);
   KD_REQUIRE(act == KD_ACT_RELU || act == KD_ACT_RELU6, KD_ERR_ARG, "kd_lidar_seg_max_fwd: needs a non-negative activation");
   SegArgs a{y, sc, sh, act, seg_start, perm, grid, nullptr, nullptr, nullptr, nullptr, nullptr, ncells, C};
@@ -747,7 +875,7 @@ int64_t kd_lidar_seg_stat_rows(int64_t ncells) { return seg_grid(ncells); }
 int kd_lidar_seg_max_bwd(const float* y, const float* sc, const float* sh, int act, const float* grid, const float* dout,
                          const float* mean, const float* invstd, const int* seg_start, const int* perm,
                          const int* row_of_point, float* G, float* partial, int64_t P, int64_t ncells, int C, void* stream) {
-  KD_REQUIRE(y && sc && sh && grid && dout && mean && invstd && seg_start && perm && row_of_point && G && partial && P > 0 && ncells > 0,
+  KD_REQUIRE(y && sc && sh && grid && dout && mean && invstd && seg_start && row_of_point && G && partial && P > 0 && ncells > 0,
              KD_ERR_ARG, "kd_lidar_seg_max_bwd: bad args");
   KD_REQUIRE(C == 64 || C == 128 || C == 256, KD_ERR_SHAPE, "kd_lidar_seg_max_bwd: C must be 64, 128 or 256 (got %d)", C);
   SegArgs a{y, sc, sh, act, seg_start, perm, const_cast<float*>(grid), dout, mean, invstd, G, partial, ncells, C};

@@ -734,6 +734,29 @@ def cell_sort(pts, B, N, H, W, rng):
     return out
 
 
+SORT_MAX_BINS = 12288            # kd_lidar_sort_points: H*W + 1 histogram bins in LDS
+
+
+def sort_points(pts, B, N, H, W, rng):
+    """Points stably sorted by (frame, cell) (kd_lidar_sort_points) -> (pts_sorted, row_sorted, seg_start).  Shared
+    between the frozen teacher and the student of one KD step exactly like cell_sort."""
+    key = ("points", pts.data_ptr(), pts._version, B, N, H, W, tuple(float(r) for r in rng), stream())
+    hit = _sort_cache.get("points")
+    if hit is not None and hit[0] == key:
+        return hit[2]
+    dev = pts.device
+    spts = torch.empty(B * N, 4, device=dev, dtype=torch.float32)
+    row_sorted = torch.empty(B * N, device=dev, dtype=torch.int32)
+    seg_start = torch.empty(B * H * W + 1, device=dev, dtype=torch.int32)
+    nbytes = lib.kd_lidar_sort_points_ws_bytes(B, N, H, W)
+    ws = ops.workspace(nbytes, dev)
+    lib.call("kd_lidar_sort_points", P(pts), B, N, H, W, float(rng[0]), float(rng[1]), float(rng[2]), float(rng[3]),
+             P(spts), P(row_sorted), P(seg_start), None, P(ws), nbytes, stream())
+    out = (spts, row_sorted, seg_start)
+    _sort_cache["points"] = (key, pts, out)
+    return out
+
+
 class LidarFn(torch.autograd.Function):
     """SpatialLiDAREncoder.forward_vectorized (lidar_encoder.py:57-99): point MLP on all B*N points
     (layer 0 on VALU, layers 1-2 as MFMA GEMMs with M = B*N), BEV binning, scatter-max."""
@@ -750,11 +773,16 @@ class LidarFn(torch.autograd.Function):
             # Inference fast path (frozen teacher): out-of-range points influence nothing in eval mode
             # (no batch statistics, never scattered), so compact them away before the point MLP.
             dev = pts.device
-            cpts = torch.empty(B * N, 4, device=dev, dtype=torch.float32)
-            ccell = torch.empty(B * N, device=dev, dtype=torch.int32)
-            if _SCATTER_MODE != "atomic":
-                # in-range points in CELL order (bins shared with the student's training scatter of the same step):
-                # the fused scatter epilogue then merges neighbouring rows in registers before touching the grid
+            cpts = ccell = None
+            if _SCATTER_MODE != "sorted" or H * W + 1 > SORT_MAX_BINS:
+                cpts = torch.empty(B * N, 4, device=dev, dtype=torch.float32)
+                ccell = torch.empty(B * N, device=dev, dtype=torch.int32)
+            if _SCATTER_MODE == "sorted" and H * W + 1 <= SORT_MAX_BINS:
+                # the head of the cell-sorted point array (shared with the student of the same step) IS the compacted
+                # list; the fused scatter epilogue merges neighbouring rows in registers before touching the grid
+                cpts, ccell, seg_start = sort_points(pts, B, N, H, W, rng)
+                counter = seg_start[B * H * W:]
+            elif _SCATTER_MODE != "atomic":
                 row_of_point, seg_start, perm = cell_sort(pts, B, N, H, W, rng)
                 counter = seg_start[B * H * W:]
                 lib.call("kd_lidar_gather_sorted", P(pts), P(perm), P(row_of_point), P(counter), P(cpts), P(ccell), B * N, stream())
@@ -779,21 +807,30 @@ class LidarFn(torch.autograd.Function):
                 lib.call("kd_lidar_scatter_max_idx_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(ccell), P(grid), B * N, C,
                          B * H * W, P(counter), stream())
             return ops.nchw_from_matrix(grid, (B, H, W))
+        mode = "atomic"
+        if units[-1].conv.weight.shape[0] in (64, 128, 256) and _SCATTER_MODE != "atomic":
+            mode = "points" if (_SCATTER_MODE == "sorted" and H * W + 1 <= SORT_MAX_BINS) else "ids"
+        seg = None
         cur = pts
+        if mode == "points":
+            # The point MLP runs on the points SORTED by (frame, cell) (stable, so every order-dependent sum keeps a
+            # fixed order): nothing downstream depends on the point order -- the grid is indexed by cell, weight
+            # gradients are sums over points -- and each cell's rows become one contiguous range.
+            cur, row_sorted, seg_start = sort_points(pts, B, N, H, W, rng)
+            seg = (row_sorted, seg_start, None)
+        elif mode == "ids":
+            seg = cell_sort(pts, B, N, H, W, rng)      # bins of point ids; the rows stay where they are
         recs = []
         for u in units:
             cur, rec = unit_forward(u, cur, training, virtual=(u.kind == "l0"))
             recs.append(rec)
-        H, W = grid_hw
         C = cur.C
         grid = torch.empty(B * H * W, C, device=pts.device, dtype=torch.float32)
-        ctx.seg = None
-        if C in (64, 128, 256) and _SCATTER_MODE != "atomic":
-            # bin the point ids by grid row once; forward max and backward tie split then run atomic-free
-            row_of_point, seg_start, perm = cell_sort(pts, B, N, H, W, rng)
-            lib.call("kd_lidar_seg_max_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(seg_start), P(perm), P(grid),
+        ctx.seg = seg
+        if seg is not None:
+            # forward max and backward tie split over the segments: atomic-free
+            lib.call("kd_lidar_seg_max_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(seg[1]), P(seg[2]), P(grid),
                      B * H * W, C, stream())
-            ctx.seg = (row_of_point, seg_start, perm)
         else:
             lib.call("kd_lidar_scatter_max_fwd", P(pts), P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(grid), B, N, C, H, W,
                      float(rng[0]), float(rng[1]), float(rng[2]), float(rng[3]), stream())

@@ -73,6 +73,43 @@ def test_cell_sort_groups_the_in_range_points_by_row(B, N, H, W, pad, nan):
     assert np.all(perm[nv:] == -7)                                              # nothing written past the end
 
 
+@pytest.mark.parametrize("B,N,H,W,pad,nan", [(1, 257, 4, 4, 0, 0), (3, 5000, 16, 16, 700, 40), (2, 9000, 64, 64, 0, 13),
+                                             (2, 40, 32, 32, 0, 0), (5, 3001, 33, 17, 100, 5), (2, 1024, 8, 8, 0, 0),
+                                             (1, 2049, 110, 110, 64, 3)])
+def test_sort_points_is_the_stable_sort_by_frame_and_cell(B, N, H, W, pad, nan):
+    from kdrt.lib import lib
+    pts = _inputs(B, N, 64, 4, pad=pad, nan=nan)[0]
+    spts = torch.full((B * N, 4), -5.0, device="cuda")
+    srow = torch.full((B * N,), -9, device="cuda", dtype=torch.int32)
+    start = torch.empty(B * H * W + 1, device="cuda", dtype=torch.int32)
+    perm = torch.full((B * N,), -7, device="cuda", dtype=torch.int32)
+    nb = lib.kd_lidar_sort_points_ws_bytes(B, N, H, W)
+    ws = torch.empty(nb, device="cuda", dtype=torch.uint8)
+    lib.call("kd_lidar_sort_points", _P(pts), B, N, H, W, *RNG, _P(spts), _P(srow), _P(start), _P(perm), _P(ws), nb, None)
+    cell = torch.empty(B * N, device="cuda", dtype=torch.int32)
+    lib.call("kd_lidar_bev_index", _P(pts), _P(cell), B * N, H, W, *RNG, None)
+    torch.cuda.synchronize()
+    cell = cell.cpu().numpy().astype(np.int64)
+    frame = np.arange(B * N) // N
+    key = np.where(cell >= 0, frame * (H * W) + cell, B * H * W + frame)     # out-of-range: after everything, by frame
+    want = np.argsort(key, kind="stable")
+    assert np.array_equal(perm.cpu().numpy(), want)
+    # bit patterns (NaN coordinates must travel unchanged)
+    assert np.array_equal(spts.cpu().numpy().view(np.int32), pts.cpu().numpy().view(np.int32)[want])
+    want_row = np.where(cell >= 0, key, -1)[want]
+    assert np.array_equal(srow.cpu().numpy(), want_row)
+    counts = np.bincount(key[cell >= 0], minlength=B * H * W)
+    assert np.array_equal(start.cpu().numpy(), np.concatenate([[0], np.cumsum(counts)]))
+
+
+def test_sort_points_rejects_a_grid_too_large_for_its_histogram():
+    from kdrt.lib import KDError, lib
+    t = torch.zeros(64, 4, device="cuda")
+    i = torch.zeros(200 * 200 + 1, device="cuda", dtype=torch.int32)
+    with pytest.raises(KDError, match="bins exceed"):
+        lib.call("kd_lidar_sort_points", _P(t), 1, 64, 200, 200, *RNG, _P(t), _P(i), _P(i), None, _P(i), 1 << 30, None)
+
+
 @pytest.mark.parametrize("C", (64, 128, 256))
 @pytest.mark.parametrize("B,N,H,W,pad,dup,nan", [(2, 3000, 16, 16, 300, 200, 20), (1, 500, 64, 64, 0, 50, 0),
                                                  (3, 20000, 64, 64, 2500, 1000, 7)])
@@ -104,6 +141,26 @@ def test_segmented_scatter_matches_atomic_scatter_bitwise(C, B, N, H, W, pad, du
     torch.cuda.synchronize()
     assert torch.equal(grid_a.view(torch.int32), grid_s.view(torch.int32))
     assert torch.equal(G_a.view(torch.int32), G_s.view(torch.int32))
+    # third form: rows physically sorted (kd_lidar_sort_points), perm = NULL
+    spts = torch.empty_like(pts)
+    srow = torch.empty(B * N, device="cuda", dtype=torch.int32)
+    start2 = torch.empty(ncells + 1, device="cuda", dtype=torch.int32)
+    perm2 = torch.empty(B * N, device="cuda", dtype=torch.int32)
+    nb2 = lib.kd_lidar_sort_points_ws_bytes(B, N, H, W)
+    ws2 = torch.empty(nb2, device="cuda", dtype=torch.uint8)
+    lib.call("kd_lidar_sort_points", _P(pts), B, N, H, W, *RNG, _P(spts), _P(srow), _P(start2), _P(perm2), _P(ws2), nb2, None)
+    ys = y[perm2.long()].contiguous()
+    grid_p = torch.full((ncells, C), -1.0, device="cuda")
+    lib.call("kd_lidar_seg_max_fwd", _P(ys), _P(sc), _P(sh), act, _P(start2), None, _P(grid_p), ncells, C, None)
+    G_p = torch.full((B * N, C), 3.0, device="cuda")
+    part_p = torch.empty(rows_s, 2, C, device="cuda")
+    lib.call("kd_lidar_seg_max_bwd", _P(ys), _P(sc), _P(sh), act, _P(grid_p), _P(dout), _P(mean), _P(invstd), _P(start2), None,
+             _P(srow), _P(G_p), _P(part_p), B * N, ncells, C, None)
+    torch.cuda.synchronize()
+    assert torch.equal(start2, start)
+    assert torch.equal(grid_a.view(torch.int32), grid_p.view(torch.int32))
+    assert torch.equal(G_a[perm2.long()].view(torch.int32), G_p.view(torch.int32))
+    assert torch.allclose(part_p.double().sum(0), part_s.double().sum(0), rtol=1e-5, atol=1e-5 * float(part_s.double().sum(0).abs().max()))
     # ties really happened, and were split
     holders = (G_s != 0).sum().item()
     occupied = ((grid_s > 0) & (dout != 0)).sum().item()
@@ -174,7 +231,7 @@ def test_lidar_encoder_same_bits_with_sorted_and_atomic_scatter(training):
     res = {}
     saved = units._SCATTER_MODE
     try:
-        for mode in ("atomic", "sorted"):
+        for mode in ("atomic", "ids", "sorted"):
             units._SCATTER_MODE = mode
             units.clear_step_caches()
             enc.zero_grad()
@@ -189,7 +246,14 @@ def test_lidar_encoder_same_bits_with_sorted_and_atomic_scatter(training):
                     res[mode] = (enc(pts).clone(), [])
     finally:
         units._SCATTER_MODE = saved
-    assert torch.equal(res["atomic"][0].view(torch.int32), res["sorted"][0].view(torch.int32))
-    for a, b in zip(res["atomic"][1], res["sorted"][1]):
-        assert bool(torch.isfinite(a).all())
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(a.abs().max()))
+    # "ids" leaves the rows in place: same bits as the atomic form.  "sorted" permutes the rows of the point MLP, so in
+    # train mode its BatchNorm statistics are summed in another order: same values to rounding.
+    assert torch.equal(res["atomic"][0].view(torch.int32), res["ids"][0].view(torch.int32))
+    if training:
+        assert torch.allclose(res["atomic"][0], res["sorted"][0], rtol=1e-5, atol=1e-5 * float(res["atomic"][0].abs().max()))
+    else:
+        assert torch.equal(res["atomic"][0].view(torch.int32), res["sorted"][0].view(torch.int32))
+    for mode in ("ids", "sorted"):
+        for a, b in zip(res["atomic"][1], res[mode][1]):
+            assert bool(torch.isfinite(a).all())
+            assert torch.allclose(a, b, rtol=2e-5, atol=2e-5 * float(a.abs().max()))
