@@ -159,6 +159,23 @@ size_t kd_lidar_sort_points_ws_bytes(int B, int64_t N, int H, int W);
 int kd_lidar_sort_points(const float* pts, int B, int64_t N, int H, int W, float x0, float x1, float y0, float y1,
                          float* pts_sorted, int* row_sorted, int* seg_start, int* perm, void* ws, size_t ws_bytes,
                          void* stream);
+/* Training backward of the last point-MLP layer WITHOUT the [points, C] scatter-max gradient (rows sorted by
+ * kd_lidar_sort_points).  kd_lidar_seg_share_bwd leaves share[cells, C] = dout / holders and the BatchNorm-backward sums;
+ * the two GEMMs rebuild G[m][c] = (rows[m] >= 0 && v > 0 && v == grid[rows[m]][c]) ? share[rows[m]][c] : 0 on load
+ * (v = act2(Y2*sc2 + sh2)) -- bit-identical to kd_lidar_seg_max_bwd + kd_pwconv_gemm(pro 2, epi 2) / kd_pwconv_wgrad
+ * (d_mode 2), minus 2.5 passes over a [points, C] tensor. */
+int kd_lidar_seg_share_bwd(const float* y, const float* sc, const float* sh, int act, const float* grid,
+                           const float* dout, const float* mean, const float* invstd, const int* seg_start,
+                           float* share, float* partial, int64_t ncells, int C, void* stream);
+int kd_lidar_l2_dgrad(const float* Y2, int64_t ldy2, const int* rows, const float* grid, const float* share,
+                      const float* al, const float* be, const float* ga, const float* sc2, const float* sh2, int act2,
+                      const float* Wt, float* G1, int64_t ldg1, const float* Y1, int64_t ldy1, const float* sc1,
+                      const float* sh1, const float* mean1, const float* invstd1, int act1, float* partial,
+                      int64_t M, int N2, int K1, void* stream);
+int kd_lidar_l2_wgrad(const float* Y2, int64_t ldy2, const int* rows, const float* grid, const float* share,
+                      const float* al, const float* be, const float* ga, const float* sc2, const float* sh2, int act2,
+                      const float* Y1, int64_t ldy1, const float* sc1, const float* sh1, int act1, float* dW,
+                      int64_t M, int N2, int K1, void* ws, size_t ws_bytes, void* stream);
 int kd_lidar_gather_sorted(const float* pts, const int* perm, const int* row_of_point, const int* nvalid_dev,
                            float* out_pts, int* out_row, int64_t P, void* stream);
 int kd_lidar_seg_max_fwd(const float* y, const float* sc, const float* sh, int act, const int* seg_start,

@@ -54,6 +54,10 @@ struct GemmArgs {
   int M, K, N;
   const int* m_dev;                   // optional: device-side row count (<= M); rows beyond it are skipped
   const float* l0w; const float* l0b; // PRO3 / EPI3: LiDAR layer-0 weight [C0][4] and bias [C0] (A or X = points [M,4])
+  // PRO4: the scatter-max gradient rebuilt on load.  A = Y raw [M,K]; trows[m] = grid row of point m (< 0: none);
+  // tmx / tshare = [cells][K] tables (cell maximum, dout / holders): G = (v > 0 && v == mx) ? share : 0 with
+  // v = act(Y*p3 + p4), then the PRO2 formula al*G + be*Y + ga.
+  const float* tmx; const float* tshare; const int* trows;
 };
 
 // Tile shape: WM x WN waves of 64x64 each (WM*WN == 4): 128x128 for wide outputs, 256x64 when the
@@ -103,7 +107,7 @@ template <int PRO, int EPI, int WM, int WN, bool SPLIT>
 // kernel; split: the 128x128 kernels except PRO2, whose two-tensor prologue would spill 46 registers).  The third
 // workgroup is worth 8-12 % on the forward kernels: these loops are latency-bound, not pipe-bound (PMC: matrix pipe
 // busy ~31 %, VALU ~10 %, LDS ~22 % at 2 workgroups / CU).
-__global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2) ? 3 : 2) : ((PRO == 2 && WM == 4) ? 2 : 3)) void pw_gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 4) ? 3 : 2) : ((PRO == 4 || (PRO == 2 && WM == 4)) ? 2 : 3)) void pw_gemm_kernel(GemmArgs g) {
   constexpr int BMt = 64 * WM, BNt = 64 * WN;
   constexpr int AF = BMt / 32, BF = BNt / 32;          // float4 loads per thread per K-tile
   constexpr int SMEM_FLOATS = SPLIT ? (BMt + BNt) * 3 * SPROW / 2 : (BMt + BNt) * LDSLD;
@@ -155,10 +159,23 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2) ? 3 : 2) : ((PR
   // a prefetch would sit behind it in the in-order vmcnt queue and drain the prefetch when first used.  Only the
   // fp32 PRO2 kernel (170-register budget at 3 workgroups/CU) fetches its five vectors at the point of use.
   // PRO3 (A = act(bn(layer0(point)))): sc, sh, the four weight rows and the bias of the thread's 4 channels
-  constexpr int NCO = PRO == 2 ? 5 : (PRO == 3 ? 7 : 2);
+  constexpr int NCO = (PRO == 2 || PRO == 4) ? 5 : (PRO == 3 ? 7 : 2);
   constexpr bool CO_LATE = PRO == 2 && !SPLIT;
   float4 ra0[AF], rb0[BF], ra1[PF2 ? AF : 1], rb1[PF2 ? BF : 1], rx[PRO >= 2 ? AF : 1], co0[NCO], co1[PF2 ? NCO : 1];
   const int c4 = tid & 7;
+  float4 rs[PRO == 4 ? AF : 1];
+  int64_t trow[PRO == 4 ? AF : 1];
+  bool tval[PRO == 4 ? AF : 1];
+  if constexpr (PRO == 4) {           // the thread's rows are the same for every K-tile: one dependent load, up front
+#pragma unroll
+    for (int i = 0; i < AF; ++i) {
+      int64_t gm = m0 + (tid >> 3) + 32 * i;
+      gm = gm < g.M ? gm : (int64_t)g.M - 1;
+      const int r = g.trows[gm];
+      tval[i] = r >= 0;
+      trow[i] = (int64_t)(r < 0 ? 0 : r) * g.K;
+    }
+  }
   auto issue_loads = [&](int kt, float4 (&ra)[AF], float4 (&rb)[BF], float4 (&co)[NCO]) {
     int gk = kt * BK + c4 * 4;
     gk = gk < g.K ? gk : g.K - 4;
@@ -168,7 +185,7 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2) ? 3 : 2) : ((PR
       for (int j = 0; j < 4; ++j) co[2 + j] = kd_ld4(g.l0w + (gk + j) * 4);
       co[6] = kd_ld4(g.l0b + gk);
     }
-    if (PRO == 2 && !CO_LATE) {
+    if ((PRO == 2 && !CO_LATE) || PRO == 4) {
       co[0] = kd_ld4(g.p0 + gk); co[1] = kd_ld4(g.p1 + gk); co[2] = kd_ld4(g.p2 + gk); co[3] = kd_ld4(g.p3 + gk); co[4] = kd_ld4(g.p4 + gk);
     }
 #pragma unroll
@@ -180,6 +197,7 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2) ? 3 : 2) : ((PR
       } else {
         ra[i] = kd_ld4(g.A + gm * g.lda + gk);
         if (PRO == 2) rx[i] = kd_ld4(g.A2 + gm * g.lda2 + gk);
+        if constexpr (PRO == 4) { rx[i] = kd_ld4(g.tmx + trow[i] + gk); rs[i] = kd_ld4(g.tshare + trow[i] + gk); }
       }
     }
 #pragma unroll
@@ -210,6 +228,14 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2) ? 3 : 2) : ((PR
         va.y = kd_bwd_operand(va.y, x.y, co[0].y, co[1].y, co[2].y, co[3].y, co[4].y, g.pro_act);
         va.z = kd_bwd_operand(va.z, x.z, co[0].z, co[1].z, co[2].z, co[3].z, co[4].z, g.pro_act);
         va.w = kd_bwd_operand(va.w, x.w, co[0].w, co[1].w, co[2].w, co[3].w, co[4].w, g.pro_act);
+      } else if constexpr (PRO == 4) {
+        const float4 x = va, mx = rx[i], sv = rs[i];
+        const float4 v = kd_affine_act4(x, co[3], co[4], g.pro_act);
+        const bool tv = tval[i];
+        va.x = kd_bwd_operand((tv && v.x > 0.f && v.x == mx.x) ? sv.x : 0.f, x.x, co[0].x, co[1].x, co[2].x, 0.f, 0.f, KD_ACT_NONE);
+        va.y = kd_bwd_operand((tv && v.y > 0.f && v.y == mx.y) ? sv.y : 0.f, x.y, co[0].y, co[1].y, co[2].y, 0.f, 0.f, KD_ACT_NONE);
+        va.z = kd_bwd_operand((tv && v.z > 0.f && v.z == mx.z) ? sv.z : 0.f, x.z, co[0].z, co[1].z, co[2].z, 0.f, 0.f, KD_ACT_NONE);
+        va.w = kd_bwd_operand((tv && v.w > 0.f && v.w == mx.w) ? sv.w : 0.f, x.w, co[0].w, co[1].w, co[2].w, 0.f, 0.f, KD_ACT_NONE);
       }
       const bool aok = kok && (m0 + (tid >> 3) + 32 * i < g.M);
       ra[i] = make_float4(aok ? va.x : 0.f, aok ? va.y : 0.f, aok ? va.z : 0.f, aok ? va.w : 0.f);
@@ -526,6 +552,9 @@ struct WgradArgs {
   int M, N, K;
   int rows_per_split;                 // multiple of the chunk height
   const float* l0w; const float* l0b; // AMODE 2: A = act(bn(layer0(point))), g.A = points [M,4]
+  // DMODE 3: D = Y raw (also the BN-backward X); the scatter-max gradient G is rebuilt from trows / tmx / tshare exactly
+  // as in pw_gemm_kernel PRO4 (msc / msh / d_act = Y's BatchNorm + activation)
+  const float* tmx; const float* tshare; const int* trows;
 };
 
 //
@@ -586,8 +615,10 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs 
   const int gn = n0 + dc4 * 4, gk = k0 + ac4 * 4;
   const bool nok = gn < g.N, kok = gk < g.K;
   const int gnc = nok ? gn : g.N - 4, gkc = kok ? gk : g.K - 4;
-  float4 cd[DMODE == 2 ? 5 : 1], ca[AMODE >= 1 ? 2 : 1], rx[DMODE == 2 ? DF4 : 1], cw[AMODE == 2 ? 4 : 1], cb = kd_zero4();
-  if (DMODE == 2) {
+  float4 cd[DMODE >= 2 ? 5 : 1], ca[AMODE >= 1 ? 2 : 1], rx[DMODE >= 2 ? DF4 : 1], cw[AMODE == 2 ? 4 : 1], cb = kd_zero4();
+  float4 rs[DMODE == 3 ? DF4 : 1];
+  int tr_cur[DMODE == 3 ? DF4 : 1], tr_nxt[DMODE == 3 ? DF4 : 1];      // grid rows of this / the next chunk's points
+  if (DMODE >= 2) {
     cd[0] = kd_ld4(g.al + gnc); cd[1] = kd_ld4(g.be + gnc); cd[2] = kd_ld4(g.ga + gnc);
     cd[3] = kd_ld4(g.msc + gnc); cd[4] = kd_ld4(g.msh + gnc);
   }
@@ -597,13 +628,34 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs 
     for (int j = 0; j < 4; ++j) cw[j] = kd_ld4(g.l0w + (gkc + j) * 4);
     cb = kd_ld4(g.l0b + gkc);
   }
+  auto load_rows = [&](int64_t mc, int (&tr)[DMODE == 3 ? DF4 : 1]) {
+    if constexpr (DMODE == 3) {
+#pragma unroll
+      for (int i = 0; i < DF4; ++i) {
+        int64_t gm = mc + (tid + 256 * i) / (TN / 4);
+        gm = gm < mend ? gm : mend - 1;
+        tr[i] = g.trows[gm];
+      }
+    }
+  };
   auto load_chunk = [&](int64_t mc) {
+    if constexpr (DMODE == 3) {
+      // the table rows of THIS chunk were fetched one chunk ago (tr_nxt): no dependent load in the steady state
+#pragma unroll
+      for (int i = 0; i < DF4; ++i) tr_cur[i] = tr_nxt[i];
+      load_rows(mc + CH < mend ? mc + CH : mc, tr_nxt);
+    }
 #pragma unroll
     for (int i = 0; i < DF4; ++i) {
       int64_t gm = mc + (tid + 256 * i) / (TN / 4);
       gm = gm < mend ? gm : mend - 1;
       rd[i] = kd_ld4(g.D + gm * g.ldd + gnc);
       if (DMODE == 2) rx[i] = kd_ld4(g.X + gm * g.ldx + gnc);
+      if constexpr (DMODE == 3) {
+        const int64_t o = (int64_t)(tr_cur[i] < 0 ? 0 : tr_cur[i]) * g.N + gnc;
+        rx[i] = kd_ld4(g.tmx + o);
+        rs[i] = kd_ld4(g.tshare + o);
+      }
     }
 #pragma unroll
     for (int i = 0; i < AF4; ++i) {
@@ -622,6 +674,14 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs 
         v.y = kd_bwd_operand(v.y, x.y, cd[0].y, cd[1].y, cd[2].y, cd[3].y, cd[4].y, g.d_act);
         v.z = kd_bwd_operand(v.z, x.z, cd[0].z, cd[1].z, cd[2].z, cd[3].z, cd[4].z, g.d_act);
         v.w = kd_bwd_operand(v.w, x.w, cd[0].w, cd[1].w, cd[2].w, cd[3].w, cd[4].w, g.d_act);
+      } else if constexpr (DMODE == 3) {
+        const float4 x = v, mx = rx[i], sv = rs[i];
+        const float4 a = kd_affine_act4(x, cd[3], cd[4], g.d_act);
+        const bool tv = tr_cur[i] >= 0;
+        v.x = kd_bwd_operand((tv && a.x > 0.f && a.x == mx.x) ? sv.x : 0.f, x.x, cd[0].x, cd[1].x, cd[2].x, 0.f, 0.f, KD_ACT_NONE);
+        v.y = kd_bwd_operand((tv && a.y > 0.f && a.y == mx.y) ? sv.y : 0.f, x.y, cd[0].y, cd[1].y, cd[2].y, 0.f, 0.f, KD_ACT_NONE);
+        v.z = kd_bwd_operand((tv && a.z > 0.f && a.z == mx.z) ? sv.z : 0.f, x.z, cd[0].z, cd[1].z, cd[2].z, 0.f, 0.f, KD_ACT_NONE);
+        v.w = kd_bwd_operand((tv && a.w > 0.f && a.w == mx.w) ? sv.w : 0.f, x.w, cd[0].w, cd[1].w, cd[2].w, 0.f, 0.f, KD_ACT_NONE);
       }
       const bool ok = nok && (mc + (tid + 256 * i) / (TN / 4) < mend);
       rd[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
@@ -636,7 +696,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs 
     }
   };
 
-  if (mbeg < mend) load_chunk(mbeg);
+  if (mbeg < mend) { load_rows(mbeg, tr_nxt); load_chunk(mbeg); }
   for (int64_t mc = mbeg; mc < mend; mc += CH) {
     transform(mc);
     kd_lds_barrier();
@@ -775,7 +835,8 @@ int launch_wgrad(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
   g.rows_per_split = (int)(cps * CH);
   nsplit = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
   const dim3 grid(ntiles * nsplit), blk(256);
-  if (g.d_mode == 2 && g.a_mode == 2) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 2, SPLIT>), grid, blk, 0, st, g);
+  if (g.d_mode == 3) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 3, 1, SPLIT>), grid, blk, 0, st, g);
+  else if (g.d_mode == 2 && g.a_mode == 2) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 2, SPLIT>), grid, blk, 0, st, g);
   else if (g.d_mode == 2 && g.a_mode == 1) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 1, SPLIT>), grid, blk, 0, st, g);
   else if (g.d_mode == 2) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 0, SPLIT>), grid, blk, 0, st, g);
   else if (g.a_mode == 1) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 0, 1, SPLIT>), grid, blk, 0, st, g);
@@ -807,6 +868,7 @@ int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {
   KD_GEMM_CASE(2, 0) KD_GEMM_CASE(2, 1) KD_GEMM_CASE(2, 2)
   KD_GEMM_CASE(3, 0) KD_GEMM_CASE(3, 1) KD_GEMM_CASE(2, 3)      // LiDAR layer 0 recomputed from the points
   KD_GEMM_CASE(1, 4)                                              // last point-MLP layer + BEV scatter-max (eval)
+  KD_GEMM_CASE(4, 2)                                              // last point-MLP layer: dgrad with G rebuilt from the tables
 #undef KD_GEMM_CASE
   return kd_check_launch("kd_pwconv_gemm");
 }
@@ -962,6 +1024,43 @@ int kd_lidar_l2_fwd_scatter(const float* A, int64_t lda, const float* sc1, const
              reinterpret_cast<const float*>(cell_idx), 0, sc2, sh2, nullptr, nullptr, act2, nullptr, (int)M, K, N, m_dev,
              nullptr, nullptr};
   return gemm_launch(g, 1, 4, st);
+}
+
+// ---- last point-MLP layer, training backward, with the scatter-max gradient G never materialised ---------------
+// (rows sorted by cell: kd_lidar_sort_points; tables from kd_lidar_seg_max_fwd (grid) / kd_lidar_seg_share_bwd (share))
+//   G[m][c]   = (rows[m] >= 0 && v > 0 && v == grid[rows[m]][c]) ? share[rows[m]][c] : 0,  v = act2(Y2[m][c]*sc2[c] + sh2[c])
+//   dy2_eff   = al*G + be*Y2 + ga                                   (BatchNorm-2 backward folded in)
+// data gradient: G1[M,K1] = (dy2_eff . W2) * act1'(Y1*sc1+sh1) with the BN1-backward sums in `partial` (Wt = W2^T [K1][N2])
+int kd_lidar_l2_dgrad(const float* Y2, int64_t ldy2, const int* rows, const float* grid, const float* share, const float* al,
+                      const float* be, const float* ga, const float* sc2, const float* sh2, int act2, const float* Wt,
+                      float* G1, int64_t ldg1, const float* Y1, int64_t ldy1, const float* sc1, const float* sh1,
+                      const float* mean1, const float* invstd1, int act1, float* partial, int64_t M, int N2, int K1,
+                      void* stream) {
+  KD_REQUIRE(Y2 && rows && grid && share && al && be && ga && sc2 && sh2 && Wt && G1 && Y1 && sc1 && sh1 && mean1 && invstd1 && partial && M > 0,
+             KD_ERR_ARG, "kd_lidar_l2_dgrad: bad args");
+  KD_REQUIRE(M < (int64_t)1 << 31 && N2 % 4 == 0 && K1 % 4 == 0 && ldy2 % 4 == 0 && ldg1 % 4 == 0 && ldy1 % 4 == 0 && N2 >= 4, KD_ERR_SHAPE,
+             "kd_lidar_l2_dgrad: channel counts and strides must be multiples of 4");
+  KD_REQUIRE(kd_aligned16(Y2) && kd_aligned16(grid) && kd_aligned16(share) && kd_aligned16(Wt) && kd_aligned16(G1) && kd_aligned16(Y1),
+             KD_ERR_ALIGN, "kd_lidar_l2_dgrad: 16-byte alignment");
+  GemmArgs g{Y2, ldy2, nullptr, 0, al, be, ga, sc2, sh2, 4, act2, Wt, nullptr, G1, ldg1, nullptr, 0,
+             Y1, ldy1, sc1, sh1, mean1, invstd1, act1, partial, (int)M, N2, K1, nullptr, nullptr, nullptr, grid, share, rows};
+  return gemm_launch(g, 4, 2, (hipStream_t)stream);
+}
+
+// weight gradient dW2[N2,K1] = dy2_eff[M,N2]^T . act1(Y1*sc1+sh1)[M,K1]
+int kd_lidar_l2_wgrad(const float* Y2, int64_t ldy2, const int* rows, const float* grid, const float* share, const float* al,
+                      const float* be, const float* ga, const float* sc2, const float* sh2, int act2, const float* Y1,
+                      int64_t ldy1, const float* sc1, const float* sh1, int act1, float* dW, int64_t M, int N2, int K1,
+                      void* ws, size_t ws_bytes, void* stream) {
+  KD_REQUIRE(Y2 && rows && grid && share && al && be && ga && sc2 && sh2 && Y1 && sc1 && sh1 && dW && ws && M > 0, KD_ERR_ARG,
+             "kd_lidar_l2_wgrad: bad args");
+  KD_REQUIRE(M < (int64_t)1 << 31 && N2 % 4 == 0 && K1 % 4 == 0 && ldy2 % 4 == 0 && ldy1 % 4 == 0, KD_ERR_SHAPE,
+             "kd_lidar_l2_wgrad: N, K, ld must be multiples of 4");
+  KD_REQUIRE(kd_aligned16(Y2) && kd_aligned16(grid) && kd_aligned16(share) && kd_aligned16(Y1) && kd_aligned16(ws), KD_ERR_ALIGN,
+             "kd_lidar_l2_wgrad: 16-byte alignment");
+  WgradArgs g{Y2, ldy2, nullptr, 0, al, be, ga, sc2, sh2, 3, act2, Y1, ldy1, sc1, sh1, 1, act1, (float*)ws,
+              (int)M, N2, K1, 0, nullptr, nullptr, grid, share, rows};
+  return wgrad_launch(g, ws_bytes, dW, (hipStream_t)stream);
 }
 
 // out[c][r] = in[r][c] -- used once per step per weight to get W^T for the dgrad GEMM.

@@ -601,7 +601,7 @@ template <int VEC> __device__ __forceinline__ void seg_st(float* p, const float 
 }
 
 // one wave per grid row; lane l owns channels [l*VEC, l*VEC + VEC)  (C == 64*VEC)
-template <int VEC>
+template <int VEC, bool PERM>
 __global__ __launch_bounds__(256) void seg_max_fwd_kernel(SegArgs a) {
   const int lane = threadIdx.x & 63;
   const int c0 = lane * VEC;
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void seg_max_fwd_kernel(SegArgs a) {
       float r[4][VEC];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int64_t p = (a.perm ? __builtin_amdgcn_readfirstlane(a.perm[i + u]) : i + u);
+        const int64_t p = (PERM ? __builtin_amdgcn_readfirstlane(a.perm[i + u]) : i + u);
         seg_ld<VEC>(r[u], a.y + p * a.C + c0);
       }
 #pragma unroll
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void seg_max_fwd_kernel(SegArgs a) {
     }
     for (; i < e; ++i) {
       float r[VEC];
-      const int64_t p = (a.perm ? __builtin_amdgcn_readfirstlane(a.perm[i]) : i);
+      const int64_t p = (PERM ? __builtin_amdgcn_readfirstlane(a.perm[i]) : i);
       seg_ld<VEC>(r, a.y + p * a.C + c0);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -645,7 +645,9 @@ __global__ __launch_bounds__(256) void seg_max_fwd_kernel(SegArgs a) {
   }
 }
 
-template <int VEC>
+// TABLE: instead of G[P, C] the kernel leaves share[ncells, C] = dout / (number of holders) (0 where nobody holds) in
+// a.G; kd_lidar_l2_dgrad / _wgrad rebuild G on the fly from (y, grid, share), so the [P, C] gradient never exists.
+template <int VEC, bool PERM, bool TABLE = false>
 __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
   __shared__ float red[4][2][64 * VEC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
       float r[4][VEC];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int64_t p = (a.perm ? __builtin_amdgcn_readfirstlane(a.perm[i + u]) : i + u);
+        const int64_t p = (PERM ? __builtin_amdgcn_readfirstlane(a.perm[i + u]) : i + u);
         seg_ld<VEC>(r[u], a.y + p * a.C + c0);
       }
 #pragma unroll
@@ -687,7 +689,7 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
     }
     for (; i < e; ++i) {
       float r[VEC];
-      const int64_t p = (a.perm ? __builtin_amdgcn_readfirstlane(a.perm[i]) : i);
+      const int64_t p = (PERM ? __builtin_amdgcn_readfirstlane(a.perm[i]) : i);
       seg_ld<VEC>(r, a.y + p * a.C + c0);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -698,6 +700,12 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
     float share[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) share[j] = d[j] / (float)cnt[j];   // only read where cnt >= 1
+    if (TABLE) {
+      float t[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) t[j] = cnt[j] > 0 ? share[j] : 0.f;
+      seg_st<VEC>(a.G + row * a.C + c0, t);
+    }
     // sweep 2: the rows come back from L2 (a cell's points were read a few hundred cycles ago)
     i = s;
     for (; i + 4 <= e; i += 4) {
@@ -705,7 +713,7 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
       int64_t p[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        p[u] = (a.perm ? __builtin_amdgcn_readfirstlane(a.perm[i + u]) : i + u);
+        p[u] = (PERM ? __builtin_amdgcn_readfirstlane(a.perm[i + u]) : i + u);
         seg_ld<VEC>(r[u], a.y + p[u] * a.C + c0);
       }
 #pragma unroll
@@ -718,12 +726,12 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
           s1[j] += g[j];
           s2[j] = fmaf(g[j], (r[u][j] - mu[j]) * inv[j], s2[j]);
         }
-        seg_st<VEC>(a.G + p[u] * a.C + c0, g);
+        if (!TABLE) seg_st<VEC>(a.G + p[u] * a.C + c0, g);
       }
     }
     for (; i < e; ++i) {
       float r[VEC], g[VEC];
-      const int64_t p = (a.perm ? __builtin_amdgcn_readfirstlane(a.perm[i]) : i);
+      const int64_t p = (PERM ? __builtin_amdgcn_readfirstlane(a.perm[i]) : i);
       seg_ld<VEC>(r, a.y + p * a.C + c0);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -732,7 +740,7 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
         s1[j] += g[j];
         s2[j] = fmaf(g[j], (r[j] - mu[j]) * inv[j], s2[j]);
       }
-      seg_st<VEC>(a.G + p * a.C + c0, g);
+      if (!TABLE) seg_st<VEC>(a.G + p * a.C + c0, g);
     }
   }
 #pragma unroll
@@ -863,9 +871,13 @@ int kd_lidar_seg_max_fwd(const float* y, const float* sc, const float* sh, int a
   SegArgs a{y, sc, sh, act, seg_start, perm, grid, nullptr, nullptr, nullptr, nullptr, nullptr, ncells, C};
   const dim3 gr(seg_grid(ncells)), bl(256);
   hipStream_t st = (hipStream_t)stream;
-  if (C == 64) hipLaunchKernelGGL(seg_max_fwd_kernel<1>, gr, bl, 0, st, a);
-  else if (C == 128) hipLaunchKernelGGL(seg_max_fwd_kernel<2>, gr, bl, 0, st, a);
-  else hipLaunchKernelGGL(seg_max_fwd_kernel<4>, gr, bl, 0, st, a);
+#define KD_SEG_LAUNCH(kern)                                                                          \
+  do {                                                                                              \
+    if (C == 64) { if (perm) hipLaunchKernelGGL((kern<1, true>), gr, bl, 0, st, a); else hipLaunchKernelGGL((kern<1, false>), gr, bl, 0, st, a); } \
+    else if (C == 128) { if (perm) hipLaunchKernelGGL((kern<2, true>), gr, bl, 0, st, a); else hipLaunchKernelGGL((kern<2, false>), gr, bl, 0, st, a); } \
+    else { if (perm) hipLaunchKernelGGL((kern<4, true>), gr, bl, 0, st, a); else hipLaunchKernelGGL((kern<4, false>), gr, bl, 0, st, a); } \
+  } while (0)
+  KD_SEG_LAUNCH(seg_max_fwd_kernel);
   return kd_check_launch("kd_lidar_seg_max_fwd");
 }
 
@@ -884,10 +896,27 @@ int kd_lidar_seg_max_bwd(const float* y, const float* sc, const float* sh, int a
   const int c4 = C / 4;
   const int64_t per_block = (int64_t)(256 / c4) * 16;
   hipLaunchKernelGGL(seg_zero_invalid_kernel, dim3((unsigned)((P + per_block - 1) / per_block)), dim3(256), 0, st, row_of_point, G, P, c4);
-  if (C == 64) hipLaunchKernelGGL(seg_max_bwd_kernel<1>, gr, bl, 0, st, a);
-  else if (C == 128) hipLaunchKernelGGL(seg_max_bwd_kernel<2>, gr, bl, 0, st, a);
-  else hipLaunchKernelGGL(seg_max_bwd_kernel<4>, gr, bl, 0, st, a);
+  KD_SEG_LAUNCH(seg_max_bwd_kernel);
+#undef KD_SEG_LAUNCH
   return kd_check_launch("kd_lidar_seg_max_bwd");
+}
+
+// Table form of kd_lidar_seg_max_bwd for rows sorted by cell (kd_lidar_sort_points; row r of `y` belongs to grid row
+// g iff seg_start[g] <= r < seg_start[g+1]): share[ncells, C] = dout / holders (rows of empty cells are not written and
+// never read), partial as in kd_lidar_seg_max_bwd.  G itself is rebuilt by kd_lidar_l2_dgrad / kd_lidar_l2_wgrad.
+int kd_lidar_seg_share_bwd(const float* y, const float* sc, const float* sh, int act, const float* grid, const float* dout,
+                           const float* mean, const float* invstd, const int* seg_start, float* share, float* partial,
+                           int64_t ncells, int C, void* stream) {
+  KD_REQUIRE(y && sc && sh && grid && dout && mean && invstd && seg_start && share && partial && ncells > 0, KD_ERR_ARG,
+             "kd_lidar_seg_share_bwd: bad args");
+  KD_REQUIRE(C == 64 || C == 128 || C == 256, KD_ERR_SHAPE, "kd_lidar_seg_share_bwd: C must be 64, 128 or 256 (got %d)", C);
+  SegArgs a{y, sc, sh, act, seg_start, nullptr, const_cast<float*>(grid), dout, mean, invstd, share, partial, ncells, C};
+  const dim3 gr(seg_grid(ncells)), bl(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 64) hipLaunchKernelGGL((seg_max_bwd_kernel<1, false, true>), gr, bl, 0, st, a);
+  else if (C == 128) hipLaunchKernelGGL((seg_max_bwd_kernel<2, false, true>), gr, bl, 0, st, a);
+  else hipLaunchKernelGGL((seg_max_bwd_kernel<4, false, true>), gr, bl, 0, st, a);
+  return kd_check_launch("kd_lidar_seg_share_bwd");
 }
 
 }  // extern "C"

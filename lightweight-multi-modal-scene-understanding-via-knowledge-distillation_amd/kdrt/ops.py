@@ -200,6 +200,33 @@ def l1_dgrad(t, y, Wt, gin, *, op: Operand, al, be, ga, msc, msh, mact, partial)
     _prof_end(e0, "pw_gemm", 2.0 * M * N1 * K0, 4.0 * (2 * M * N1 + M * K0 + M * 4 + N1 * K0), None, M)
 
 
+def l2_dgrad(tables, out_op: Operand, Wt, gin, *, inp: Operand, al, be, ga, partial):
+    """Data gradient of the last point-MLP layer with the scatter-max gradient rebuilt from (row_sorted, grid, share)."""
+    rows_t, grid, share = tables
+    y = out_op.raw
+    M, N = y.shape
+    K = inp.C
+    t0 = _prof_begin()
+    lib.call("kd_lidar_l2_dgrad", P(y), ld(y), P(rows_t), P(grid), P(share), P(al), P(be), P(ga), P(out_op.sc), P(out_op.sh),
+             out_op.act, P(Wt), P(gin), ld(gin), P(inp.raw), ld(inp.raw), P(inp.sc), P(inp.sh), P(inp.bnc.mean), P(inp.bnc.invstd),
+             inp.act, P(partial), M, N, K, stream())
+    # algorithmic traffic: Y2 in, Y1 in (epilogue mask), G1 out; the tables are cache-resident (one row per ~12 points)
+    _prof_end(t0, "pw_gemm", 2.0 * M * N * K, 4.0 * (M * N + 2 * M * K + M + N * K), None, M)
+
+
+def l2_wgrad(tables, out_op: Operand, dW, *, inp: Operand, al, be, ga):
+    rows_t, grid, share = tables
+    y = out_op.raw
+    M, N = y.shape
+    K = inp.C
+    nbytes = lib.kd_pwconv_wgrad_ws_bytes(M, N, K)
+    ws = workspace(nbytes, y.device)
+    t0 = _prof_begin()
+    lib.call("kd_lidar_l2_wgrad", P(y), ld(y), P(rows_t), P(grid), P(share), P(al), P(be), P(ga), P(out_op.sc), P(out_op.sh),
+             out_op.act, P(inp.raw), ld(inp.raw), P(inp.sc), P(inp.sh), inp.act, P(dW), M, N, K, P(ws), nbytes, stream())
+    _prof_end(t0, "pw_wgrad", 2.0 * M * N * K, 4.0 * (M * N + M * K + M + N * K), None, M)
+
+
 def l1_wgrad(t, y, dW, *, op: Operand, al, be, ga, msc, msh, mact):
     pts, w0, b0 = op.virt
     M, N, K = pts.shape[0], y.shape[1], w0.shape[0]

@@ -182,9 +182,14 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
         if mact == ACT_NONE:
             msc = msh = None
     else:
+        # "G": t = masked gradient [M, C];  "GS": t = (row_sorted, grid, share) -- the LiDAR scatter-max gradient as
+        # per-cell tables, rebuilt on load by kd_lidar_l2_dgrad / _wgrad (only a "pw" unit with a deferred input takes it)
         t, partial, rows = g[1], g[2], g[3]
         pstride = g[4] if len(g) > 4 else None
         msc, msh, mact = None, None, ACT_NONE
+    tables = g[0] == "GS"
+    if tables and not (spec.kind == "pw" and rec.inp.virt is None and rec.inp.bnc is not None):
+        raise KDError("table-form scatter gradient needs a pointwise unit with a deferred input")
     beta_p = spec.bn.bias
     g_buf, g_dir = gradsink.out_for(rec.gamma)
     b_buf, b_dir = gradsink.out_for(beta_p)
@@ -201,7 +206,9 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
         inp = rec.inp
         N, K = C, inp.C
         dW, w_dir = gradsink.out_for(rec.w)
-        if inp.virt is not None:
+        if tables:
+            ops.l2_wgrad(t, out_op, dW, inp=inp, al=al, be=be, ga=ga)
+        elif inp.virt is not None:
             ops.l1_wgrad(t, y, dW, op=inp, al=al, be=be, ga=ga, msc=msc, msh=msh, mact=mact)
         else:
             ops.pw_wgrad(t, inp.raw, dW, M=M, N=N, K=K, X=y, d_mode=2, d_act=mact, al=al, be=be, ga=ga, msc=msc, msh=msh,
@@ -215,6 +222,12 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
                 rows_in = lib.kd_pwconv_stat_rows(M)
                 part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
                 ops.l1_dgrad(t, y, Wt, gin, op=inp, al=al, be=be, ga=ga, msc=msc, msh=msh, mact=mact, partial=part_in)
+                g_in = ("G", gin, part_in, rows_in)
+            elif tables:
+                gin = torch.empty(M, K, device=dev, dtype=torch.float32)
+                rows_in = lib.kd_pwconv_stat_rows(M)
+                part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
+                ops.l2_dgrad(t, out_op, Wt, gin, inp=inp, al=al, be=be, ga=ga, partial=part_in)
                 g_in = ("G", gin, part_in, rows_in)
             elif inp.bnc is not None:
                 gin = torch.empty(M, K, device=dev, dtype=torch.float32)
@@ -703,6 +716,9 @@ def run_x4_head(x, units, cls_conv, training):
 # training scatter-max: "sorted" (cell-sorted segments, default) or "atomic" (kept for A/B and for widths the
 # segmented kernels do not cover)
 _SCATTER_MODE = os.environ.get("KD_SCATTER", "sorted")
+# with sorted points: hand the scatter-max gradient to the last layer's backward GEMMs as per-cell tables (default) or
+# as the materialised [points, C] tensor ("0": A/B and tests)
+_SCATTER_TABLES = os.environ.get("KD_SCATTER_TABLES", "1") != "0"
 
 
 _sort_cache: dict = {}
@@ -844,6 +860,18 @@ class LidarFn(torch.autograd.Function):
         cur, pts, rng = ctx.last, ctx.pts, ctx.rng
         dev = dm.device
         Pn = B * N
+        last = ctx.recs[-1]
+        if (ctx.seg is not None and ctx.seg[2] is None and _SCATTER_TABLES and last.spec.kind == "pw"
+                and last.inp.virt is None and last.inp.bnc is not None):
+            # rows sorted by cell: the [points, C] gradient is never written -- per-cell tables instead
+            row_sorted, seg_start, _ = ctx.seg
+            rows = lib.kd_lidar_seg_stat_rows(B * H * W)
+            partial = torch.empty(rows * 2 * C, device=dev, dtype=torch.float32)
+            share = torch.empty(B * H * W, C, device=dev, dtype=torch.float32)
+            lib.call("kd_lidar_seg_share_bwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(ctx.grid), P(dm), P(cur.bnc.mean),
+                     P(cur.bnc.invstd), P(seg_start), P(share), P(partial), B * H * W, C, stream())
+            grads, _ = chain_backward(ctx.recs, ("GS", (row_sorted, ctx.grid, share), partial, rows), need_input_grad=False)
+            return (None, None, None, None, None, *grads)
         G = torch.empty(Pn, C, device=dev, dtype=torch.float32)
         if ctx.seg is not None:
             row_of_point, seg_start, perm = ctx.seg

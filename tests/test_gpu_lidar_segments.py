@@ -229,10 +229,11 @@ def test_lidar_encoder_same_bits_with_sorted_and_atomic_scatter(training):
     # (NaN / Inf coordinates only in eval: in train mode they poison the batch statistics, in the reference too)
     pts = _inputs(2, 6000, 64, 21, pad=500, dup=300, nan=0 if training else 9)[0].view(2, 6000, 4)
     res = {}
-    saved = units._SCATTER_MODE
+    saved = units._SCATTER_MODE, units._SCATTER_TABLES
     try:
-        for mode in ("atomic", "ids", "sorted"):
-            units._SCATTER_MODE = mode
+        for mode in ("atomic", "ids", "sorted", "sorted_G"):
+            units._SCATTER_MODE = mode.split("_")[0]
+            units._SCATTER_TABLES = mode == "sorted"        # "sorted_G": sorted rows, gradient materialised as [points, C]
             units.clear_step_caches()
             enc.zero_grad()
             if training:
@@ -245,7 +246,11 @@ def test_lidar_encoder_same_bits_with_sorted_and_atomic_scatter(training):
                 with torch.no_grad():
                     res[mode] = (enc(pts).clone(), [])
     finally:
-        units._SCATTER_MODE = saved
+        units._SCATTER_MODE, units._SCATTER_TABLES = saved
+    # the table form of the scatter gradient rebuilds exactly the values the materialised form stores
+    assert torch.equal(res["sorted"][0].view(torch.int32), res["sorted_G"][0].view(torch.int32))
+    for a, b in zip(res["sorted"][1], res["sorted_G"][1]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     # "ids" leaves the rows in place: same bits as the atomic form.  "sorted" permutes the rows of the point MLP, so in
     # train mode its BatchNorm statistics are summed in another order: same values to rounding.
     assert torch.equal(res["atomic"][0].view(torch.int32), res["ids"][0].view(torch.int32))

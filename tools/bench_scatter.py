@@ -51,5 +51,12 @@ timed("cell sort", lambda: lib.call("kd_lidar_cell_sort", P(pts), B, N, H, W, *R
 timed("segmented fwd", lambda: lib.call("kd_lidar_seg_max_fwd", P(y), P(sc), P(sh), 1, P(start), P(perm), P(grid), nc, C, None))
 timed("segmented bwd (+zero rows)", lambda: lib.call("kd_lidar_seg_max_bwd", P(y), P(sc), P(sh), 1, P(grid), P(dout), P(mean), P(invstd),
                                                      P(start), P(perm), P(row), P(G), P(part_s), B * N, nc, C, None))
+spts, srow, start2 = torch.empty_like(pts), torch.empty(B * N, device="cuda", dtype=torch.int32), torch.empty(nc + 1, device="cuda", dtype=torch.int32)
+wpn = lib.kd_lidar_sort_points_ws_bytes(B, N, H, W)
+wp = torch.empty(wpn, device="cuda", dtype=torch.uint8)
+timed("stable point sort", lambda: lib.call("kd_lidar_sort_points", P(pts), B, N, H, W, *RNG, P(spts), P(srow), P(start2), None, P(wp), wpn, None))
+timed("segmented fwd, sorted rows", lambda: lib.call("kd_lidar_seg_max_fwd", P(y), P(sc), P(sh), 1, P(start2), None, P(grid), nc, C, None))
+timed("segmented bwd, sorted rows", lambda: lib.call("kd_lidar_seg_max_bwd", P(y), P(sc), P(sh), 1, P(grid), P(dout), P(mean), P(invstd),
+                                                     P(start2), None, P(srow), P(G), P(part_s), B * N, nc, C, None))
 nv = int(start[-1])
 print(f"in-range points: {nv} of {B * N}; ideal bytes fwd {nv * C * 4 / 1e9:.2f} GB, bwd {(2 * nv + (B * N - nv)) * C * 4 / 1e9:.2f} GB")
