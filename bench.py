@@ -240,7 +240,7 @@ def main():
         }
         # HBM bytes per launch come from PMC counters, which need their own rocprofv3 passes: use the committed
         # measurement of this exact workload (profiles/), null for any other configuration
-        for fn in ("r01_bench_pmc_traffic_B256.json", "r01_bench_pmc_traffic_B128.json"):
+        for fn in ("r01_bench_pmc_traffic_B256.json",):      # (the B=128 file predates the sorted-points LiDAR path)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 wl = pmc["workload"]
