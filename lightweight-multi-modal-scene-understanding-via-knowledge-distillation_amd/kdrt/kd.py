@@ -29,13 +29,16 @@ class KDStep:
             p.requires_grad_(False)
 
     def __call__(self, images, points, labels):
-        units.clear_step_caches()          # the teacher/student share of the point bins never outlives one step
-        with torch.no_grad():
-            zt, mt = self.teacher(images, points, return_intermediates=True)
-        gradsink.active = self.sink
-        self.sink.begin_step()
-        self.opt.zero_grad()
-        zs, ms = self.student(images, points, return_intermediates=True)
+        units.share_point_bins(True)       # teacher and student of THIS step sort the same points once ...
+        try:
+            with torch.no_grad():
+                zt, mt = self.teacher(images, points, return_intermediates=True)
+            gradsink.active = self.sink
+            self.sink.begin_step()
+            self.opt.zero_grad()
+            zs, ms = self.student(images, points, return_intermediates=True)
+        finally:
+            units.share_point_bins(False)  # ... and nothing of it outlives the two forward passes
         total, parts = kd_objective(zs, ms, zt, mt, labels, self.cw, self.T, self.alpha, self.beta, self.ignore_index)
         total.backward()
         self.opt.grad_scale = self.reducer.finish() if self.reducer is not None else 1.0

@@ -722,10 +722,21 @@ _SCATTER_TABLES = os.environ.get("KD_SCATTER_TABLES", "1") != "0"
 
 
 _sort_cache: dict = {}
+_sort_sharing = False
+
+
+def share_point_bins(on: bool):
+    """kdrt.kd brackets teacher forward + student forward of ONE KD step with share_point_bins(True) ... (False): only
+    inside that bracket may the second LiDAR encoder reuse the first one's sort of the same point tensor.  Outside it
+    (plain module calls, the reference-style trainer) every call sorts for itself -- a tensor refilled through a raw
+    pointer between two calls could not be told from an unchanged one.  Entering or leaving drops the entries, so
+    nothing computed for one step ever serves the next."""
+    global _sort_sharing
+    _sort_sharing = bool(on)
+    _sort_cache.clear()
 
 
 def clear_step_caches():
-    """Called by kdrt.kd at the start of every KD step: nothing computed for one step may serve the next."""
     _sort_cache.clear()
 
 
@@ -734,7 +745,7 @@ def cell_sort(pts, B, N, H, W, rng):
     the student of ONE KD step see the same point tensor, so the second caller reuses the first one's bins; the entry
     keeps the tensor alive (its address cannot be recycled) and is dropped on any in-place write or at the next step."""
     key = (pts.data_ptr(), pts._version, B, N, H, W, tuple(float(r) for r in rng), stream())
-    hit = _sort_cache.get("entry")
+    hit = _sort_cache.get("entry") if _sort_sharing else None
     if hit is not None and hit[0] == key:
         return hit[2]
     dev = pts.device
@@ -746,7 +757,8 @@ def cell_sort(pts, B, N, H, W, rng):
     lib.call("kd_lidar_cell_sort", P(pts), B, N, H, W, float(rng[0]), float(rng[1]), float(rng[2]), float(rng[3]),
              P(row_of_point), P(seg_start), P(perm), P(ws), nbytes, stream())
     out = (row_of_point, seg_start, perm)
-    _sort_cache["entry"] = (key, pts, out)
+    if _sort_sharing:
+        _sort_cache["entry"] = (key, pts, out)
     return out
 
 
@@ -757,7 +769,7 @@ def sort_points(pts, B, N, H, W, rng):
     """Points stably sorted by (frame, cell) (kd_lidar_sort_points) -> (pts_sorted, row_sorted, seg_start).  Shared
     between the frozen teacher and the student of one KD step exactly like cell_sort."""
     key = ("points", pts.data_ptr(), pts._version, B, N, H, W, tuple(float(r) for r in rng), stream())
-    hit = _sort_cache.get("points")
+    hit = _sort_cache.get("points") if _sort_sharing else None
     if hit is not None and hit[0] == key:
         return hit[2]
     dev = pts.device
@@ -769,7 +781,8 @@ def sort_points(pts, B, N, H, W, rng):
     lib.call("kd_lidar_sort_points", P(pts), B, N, H, W, float(rng[0]), float(rng[1]), float(rng[2]), float(rng[3]),
              P(spts), P(row_sorted), P(seg_start), None, P(ws), nbytes, stream())
     out = (spts, row_sorted, seg_start)
-    _sort_cache["points"] = (key, pts, out)
+    if _sort_sharing:
+        _sort_cache["points"] = (key, pts, out)
     return out
 
 

@@ -101,3 +101,38 @@ def test_graphed_kd_step_matches_eager():
         assert torch.allclose(p1, p2, atol=1e-6, rtol=1e-5), n1
     for (n1, b1), (_, b2) in zip(s_e.named_buffers(), s_g.named_buffers()):
         assert torch.allclose(b1.float(), b2.float(), atol=1e-6, rtol=1e-5), n1
+
+
+def test_point_sort_is_shared_inside_one_kd_step_only(monkeypatch):
+    """Teacher and student of one KD step sort the same point tensor ONCE; every step sorts again (nothing is carried
+    over, so the bench's timed region contains the sort), and plain module calls outside a KD step never share."""
+    import kd_oracle as O
+    from _gpu_util import build_product, load_random_state
+    from kdrt import units
+    from kdrt.kd import KDStep
+    from kdrt.lib import lib
+    from kdrt.optim import FusedAdamW
+    B, HW, N, G = 2, 64, 512, 16
+    images, pts, labels = O.make_inputs(B, HW, N, G, 4, pad_tail=40)
+    images, pts, labels = images.cuda(), pts.cuda(), labels.cuda()
+    teacher = build_product("concat", G); load_random_state(teacher, "concat", 11)
+    student = build_product("weighted", G); load_random_state(student, "weighted", 12); student.train()
+    opt = FusedAdamW(student.parameters(), lr=1e-3, weight_decay=1e-3)
+    step = KDStep(student, teacher.eval(), opt, torch.tensor([0.4, 3.5]).cuda())
+    calls = []
+    real = type(lib).call
+
+    def counting(self, name, *a):
+        calls.append(name)
+        return real(self, name, *a)
+
+    monkeypatch.setattr(type(lib), "call", counting)
+    for expect in (1, 2, 3):
+        step(images, pts, labels)
+        assert calls.count("kd_lidar_sort_points") == expect
+    assert not units._sort_cache and not units._sort_sharing
+    calls.clear()
+    with torch.no_grad():
+        teacher(images, pts)
+        teacher(images, pts)
+    assert calls.count("kd_lidar_sort_points") == 2
