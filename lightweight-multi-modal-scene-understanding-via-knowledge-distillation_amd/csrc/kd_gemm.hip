@@ -435,6 +435,7 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 4) ? 3
     const bool hb = g.bias != nullptr;
     bias4 = make_float4(hb ? bv.x : 0.f, hb ? bv.y : 0.f, hb ? bv.z : 0.f, hb ? bv.w : 0.f);
     if (EPI_BWD) { esc = kd_ld4(g.esc + colc); esh = kd_ld4(g.esh + colc); emean = kd_ld4(g.emean + colc); einv = kd_ld4(g.einv + colc); }
+    if (EPI == 5) { esc = kd_ld4(g.esc + colc); esh = kd_ld4(g.esh + colc); }
   }
   float4 ew[EPI == 3 ? 4 : 1], eb = kd_zero4();      // EPI3: X is layer 0 of the point, recomputed for the thread's 4 columns
   if (EPI == 3) {
@@ -459,7 +460,19 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 4) ? 3
     KD_PHE(2);
     // All global LOADS of this half are issued before its first store (clamped addresses, no branches), so no
     // wait on a load ever has an older store in front of it in the in-order vmcnt queue.
-    float4 xr[EPI_BWD ? NI : 1];
+    float4 xr[(EPI_BWD || EPI == 5) ? NI : 1];
+    if (EPI == 5) {                                  // EPI5: the residual is added AFTER BatchNorm + activation
+      const bool has = g.addend != nullptr;
+      const float* ap = has ? g.addend : g.W;        // any valid address; the value is dropped by the select
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int rr = rg + RG * i;
+        int64_t row = m0 + (rr >> 5) * 64 + h * 32 + (rr & 31);
+        row = row < g.M ? row : (int64_t)g.M - 1;
+        const float4 ad = kd_ld4(ap + (has ? row * g.ldadd + colc : 0));
+        xr[i] = make_float4(has ? ad.x : 0.f, has ? ad.y : 0.f, has ? ad.z : 0.f, has ? ad.w : 0.f);
+      }
+    }
     if (EPI_BWD) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -469,7 +482,7 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 4) ? 3
         xr[i] = EPI == 3 ? kd_ld4(g.X + row * 4) : kd_ld4(g.X + row * g.ldx + colc);
       }
     }
-    if (g.addend) {                                  // residual gradient: folded into the staged tile (own elements only)
+    if (EPI != 5 && g.addend) {                      // residual gradient: folded into the staged tile (own elements only)
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int rr = rg + RG * i;
@@ -502,6 +515,11 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 4) ? 3
           s2.z = fmaf(v.z, (x.z - emean.z) * einv.z, s2.z);
           s2.w = fmaf(v.w, (x.w - emean.w) * einv.w, s2.w);
         }
+      } else if (EPI == 5) {
+        // inference finish: eval-mode BatchNorm + activation (+ residual) applied here, same operation order as the
+        // separate kd_bn_act_apply pass (act(fma(raw, sc, sh)) + res on the fp32-rounded raw value): identical bits
+        v = kd_affine_act4(v, esc, esh, g.epi_act);
+        v.x += xr[i].x; v.y += xr[i].y; v.z += xr[i].z; v.w += xr[i].w;
       } else if (EPI == 1) {
         if (ok) {
           s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
@@ -511,7 +529,7 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 4) ? 3
       if (ok) kd_st4(g.C + row * g.ldc + col, v);
     }
   }
-  if (EPI != 0) {
+  if (EPI != 0 && EPI != 5) {
     kd_lds_barrier();
     float* red = smem;                               // [RG row groups][2 stats][BNt columns]
     kd_st4(red + (rg * 2 + 0) * BNt + c4e * 4, s1);
@@ -868,6 +886,7 @@ int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {
   KD_GEMM_CASE(2, 0) KD_GEMM_CASE(2, 1) KD_GEMM_CASE(2, 2)
   KD_GEMM_CASE(3, 0) KD_GEMM_CASE(3, 1) KD_GEMM_CASE(2, 3)      // LiDAR layer 0 recomputed from the points
   KD_GEMM_CASE(1, 4)                                              // last point-MLP layer + BEV scatter-max (eval)
+  KD_GEMM_CASE(0, 5) KD_GEMM_CASE(1, 5)                           // inference: eval BatchNorm + act (+ residual) in the epilogue
   KD_GEMM_CASE(4, 2)                                              // last point-MLP layer: dgrad with G rebuilt from the tables
 #undef KD_GEMM_CASE
   return kd_check_launch("kd_pwconv_gemm");
@@ -920,13 +939,14 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
              "kd_pwconv_gemm: N=%d and the output-side row strides must be multiples of 4", N);
   KD_REQUIRE(kd_aligned16(A) && kd_aligned16(W) && kd_aligned16(C) && kd_aligned16(addend) && kd_aligned16(X) &&
              kd_aligned16(bias), KD_ERR_ALIGN, "kd_pwconv_gemm: A/W/C/addend/X/bias must be 16-byte aligned");
-  KD_REQUIRE(pro >= 0 && pro <= 2 && epi >= 0 && epi <= 2, KD_ERR_ARG, "kd_pwconv_gemm: bad pro/epi");
+  KD_REQUIRE(pro >= 0 && pro <= 2 && ((epi >= 0 && epi <= 2) || epi == 5), KD_ERR_ARG, "kd_pwconv_gemm: bad pro/epi");
+  if (epi == 5) KD_REQUIRE(pro <= 1 && esc && esh && kd_aligned16(esc) && kd_aligned16(esh), KD_ERR_ARG, "kd_pwconv_gemm: EPI5 needs pro 0/1 and sc, sh");
   if (pro == 1) KD_REQUIRE(p0 && p1 && kd_aligned16(p0) && kd_aligned16(p1), KD_ERR_ARG, "kd_pwconv_gemm: PRO1 needs sc/sh");
   if (pro == 2) {
     KD_REQUIRE(A2 && p0 && p1 && p2 && lda2 % 4 == 0 && kd_aligned16(A2), KD_ERR_ARG, "kd_pwconv_gemm: PRO2 needs X, al, be, ga");
     KD_REQUIRE(pro_act == KD_ACT_NONE || (p3 && p4), KD_ERR_ARG, "kd_pwconv_gemm: PRO2 mask needs sc/sh");
   }
-  if (epi != 0) KD_REQUIRE(partial, KD_ERR_ARG, "kd_pwconv_gemm: stats epilogue needs a partial slab");
+  if (epi == 1 || epi == 2) KD_REQUIRE(partial, KD_ERR_ARG, "kd_pwconv_gemm: stats epilogue needs a partial slab");
   if (epi == 2) KD_REQUIRE(X && esc && esh && emean && einv, KD_ERR_ARG, "kd_pwconv_gemm: EPI2 needs X, sc, sh, mean, invstd");
   if (pro == 2 && !p3) { p3 = p0; p4 = p0; }          // mask disabled (act none): any valid vector will do
   KD_REQUIRE(K >= 4, KD_ERR_SHAPE, "kd_pwconv_gemm: K must be >= 4");

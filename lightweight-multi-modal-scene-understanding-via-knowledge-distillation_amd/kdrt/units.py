@@ -166,6 +166,34 @@ def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] 
     return Operand(y, rec.out_geom, rec.bnc, spec.act), rec
 
 
+def run_mode(training: bool) -> int:
+    """0 eval with autograd, 1 training, 2 inference (eval AND grad mode off).  Evaluated by the run_* wrappers: inside
+    autograd.Function.forward grad mode is always off, so the Functions cannot tell 0 from 2 themselves."""
+    return 1 if training else (0 if torch.is_grad_enabled() else 2)
+
+
+def inference_tail_ok(units, infer: bool) -> bool:
+    """True when a chain may end in the fused inference epilogue: eval-mode BatchNorm statistics are known before the
+    GEMM runs, and without autograd nobody needs the raw conv output afterwards."""
+    return infer and len(units) > 0 and units[-1].kind == "pw"
+
+
+def pw_forward_final(spec: UnitSpec, inp: Operand, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Inference tail of a chain: 1x1 conv + eval BatchNorm + activation (+ residual) in ONE GEMM (epilogue 5 of
+    kd_pwconv_gemm) -- the same values, bit for bit, as the raw GEMM followed by kd_bn_act_apply, minus one pass."""
+    w, b = spec.conv.weight, spec.conv.bias
+    N, K = w.shape[0], w.shape[1]
+    if inp.C != K:
+        raise KDError(f"pointwise conv expects {K} input channels, got {inp.C}")
+    dev = w.device
+    bnc = _coeffs(spec, None, 0, N, inp.M, False, None, dev)
+    y = torch.empty(inp.M, N, device=dev, dtype=torch.float32)
+    ops.pw_gemm(inp.raw, w, y, M=inp.M, K=K, N=N, pro=1 if inp.bnc is not None else 0, pro_act=inp.act,
+                p=(inp.sc, inp.sh, None, None, None), bias=b, addend=res, epi=5, esc=bnc.scale, esh=bnc.shift,
+                epi_act=spec.act)
+    return y
+
+
 def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[torch.Tensor] = None):
     """g: ("D", dA) unmasked gradient w.r.t. the activated output, or ("G", G, partial, rows[, pstride])
     already masked with BN-backward sums.  Returns (param grads aligned with spec.params(), g_in) where
@@ -347,6 +375,7 @@ class ChainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, units, residual, training, *params):
+        infer, training = training == 2, training == 1
         recs = []
         if units[0].kind == "stem":
             ops.require_gpu_tensor(x, "TwinLiteEncoder")
@@ -354,6 +383,11 @@ class ChainFn(torch.autograd.Function):
         else:
             xm, geom = ops.nhwc_view(x)
             cur = Operand(xm, geom)
+        if inference_tail_ok(units, infer):
+            for u in units[:-1]:
+                cur, _ = unit_forward(u, cur, training)
+            out = pw_forward_final(units[-1], cur, res=xm if residual else None)
+            return ops.nchw_from_matrix(out, cur.geom)
         for u in units:
             cur, rec = unit_forward(u, cur, training)
             recs.append(rec)
@@ -374,7 +408,7 @@ class ChainFn(torch.autograd.Function):
 
 
 def run_chain(x, units: Sequence[UnitSpec], residual: bool, training: bool):
-    return ChainFn.apply(x, list(units), residual, training, *_params_of(units))
+    return ChainFn.apply(x, list(units), residual, run_mode(training), *_params_of(units))
 
 
 # =================================================================================================
@@ -384,6 +418,7 @@ class FPNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, n_stage, laterals, post_units, training, target_size, *tensors):
+        infer, training = training == 2, training == 1
         feats = tensors[:n_stage]
         lat_ops, lat_recs, in_geoms = [], [], []
         for f, u in zip(feats, laterals):
@@ -401,6 +436,10 @@ class FPNFn(torch.autograd.Function):
                      Ho, Wo, Ct, stream())
         cur = Operand(fused, (B, Ho, Wo))
         post_recs = []
+        if inference_tail_ok(post_units, infer):
+            for u in post_units[:-1]:
+                cur, _ = unit_forward(u, cur, training)
+            return ops.nchw_from_matrix(pw_forward_final(post_units[-1], cur), cur.geom)
         for u in post_units:
             cur, rec = unit_forward(u, cur, training)
             post_recs.append(rec)
@@ -431,7 +470,7 @@ class FPNFn(torch.autograd.Function):
 
 def run_fpn(feats: Sequence[torch.Tensor], laterals: Sequence[UnitSpec], post_units: Sequence[UnitSpec], training,
             target_size=None):
-    return FPNFn.apply(len(feats), list(laterals), list(post_units), training,
+    return FPNFn.apply(len(feats), list(laterals), list(post_units), run_mode(training),
                        tuple(target_size) if target_size is not None else None, *feats, *_params_of(laterals),
                        *_params_of(post_units))
 
@@ -502,10 +541,17 @@ class ConcatFuseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cam, lid, u_cam, u_lid, fuse_units, training, *params):
+        infer, training = training == 2, training == 1
         cat, comb, (op_c, rec_c), (op_l, rec_l), geom = _proj_pair(cam, lid, u_cam, u_lid, training)
         cur = Operand(cat, geom, comb, ACT_RELU)
         pre = ops.materialize(cur)
         recs = []
+        if inference_tail_ok(fuse_units, infer):
+            for u in fuse_units[:-1]:
+                cur, _ = unit_forward(u, cur, training)
+            pre_t = ops.nchw_from_matrix(pre, geom)
+            ctx.mark_non_differentiable(pre_t)
+            return ops.nchw_from_matrix(pw_forward_final(fuse_units[-1], cur), geom), pre_t
         for u in fuse_units:
             cur, rec = unit_forward(u, cur, training)
             recs.append(rec)
@@ -527,7 +573,7 @@ class ConcatFuseFn(torch.autograd.Function):
 
 
 def run_concat_fuse(cam, lid, u_cam, u_lid, fuse_units, training):
-    return ConcatFuseFn.apply(cam, lid, u_cam, u_lid, list(fuse_units), training, *u_cam.params(), *u_lid.params(),
+    return ConcatFuseFn.apply(cam, lid, u_cam, u_lid, list(fuse_units), run_mode(training), *u_cam.params(), *u_lid.params(),
                               *_params_of(fuse_units))
 
 
@@ -792,13 +838,14 @@ class LidarFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, points, units, grid_hw, rng, training, *params):
+        infer, training = training == 2, training == 1
         ops.require_gpu_tensor(points, "LiDAREncoder")
         B, N, D = points.shape
         if D != 4:
             raise KDError(f"LiDAR points must be [B, N, 4], got {tuple(points.shape)}")
         pts = points.contiguous().view(B * N, 4)
         H, W = grid_hw
-        if not training and not torch.is_grad_enabled():
+        if infer:
             # Inference fast path (frozen teacher): out-of-range points influence nothing in eval mode
             # (no batch statistics, never scattered), so compact them away before the point MLP.
             dev = pts.device
@@ -905,4 +952,4 @@ class LidarFn(torch.autograd.Function):
 
 
 def run_lidar(points, units, grid_hw, rng, training):
-    return LidarFn.apply(points, list(units), tuple(grid_hw), tuple(rng), training, *_params_of(units))
+    return LidarFn.apply(points, list(units), tuple(grid_hw), tuple(rng), run_mode(training), *_params_of(units))

@@ -226,3 +226,23 @@ def test_kd_gradients_against_fp64_oracle():
     gpu = rel({n: p.grad for n, p in student.named_parameters()})
     assert len(keys) > 80
     assert gpu[len(gpu) // 2] <= max(3 * cpu[len(cpu) // 2], 1e-5) and gpu[-1] <= max(3 * cpu[-1], 5e-5), (gpu[len(gpu) // 2], gpu[-1], cpu[len(cpu) // 2], cpu[-1])
+
+
+@pytest.mark.parametrize("fusion", ("concat", "minimal", "weighted"))
+def test_inference_epilogue_same_bits_as_two_pass_eval(fusion):
+    """Under no_grad the tail of every eval-mode chain (1x1 conv + BatchNorm + activation + residual) runs inside the GEMM
+    epilogue; with autograd on, the same model takes the raw-GEMM + apply path.  Same bits, logits and intermediates."""
+    from _gpu_util import build_product, load_random_state
+    G = 16
+    images, pts, _ = O.make_inputs(2, 64, 700, G, 5, pad_tail=60)
+    images, pts = images.cuda(), pts.cuda()
+    model = build_product(fusion, G)
+    load_random_state(model, fusion, 21)
+    model.eval()
+    with torch.no_grad():
+        z1, m1 = model(images, pts, return_intermediates=True)
+    z2, m2 = model(images, pts, return_intermediates=True)          # grad mode: two-pass tails
+    assert torch.equal(z1.view(torch.int32), z2.detach().view(torch.int32))
+    assert m1.keys() == m2.keys()
+    for k in m1:
+        assert torch.equal(m1[k].view(torch.int32), m2[k].detach().view(torch.int32)), k

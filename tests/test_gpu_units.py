@@ -148,6 +148,26 @@ def test_lidar_encoder(n, grid, pad):
         assert max_err(p.grad, want)[1] < 5 * TOL, name
 
 
+def test_lidar_encoder_eval_mode_backward():
+    """eval() with autograd on (frozen-BatchNorm fine-tuning): running statistics in the forward, real gradients back."""
+    from src.models.lidar_encoder import LiDAREncoder
+    enc = LiDAREncoder(encoder_type="spatial", grid_size=(16, 16))
+    st = _rand_state(enc, 33)
+    enc = enc.cuda().eval()
+    _, pts, _ = O.make_inputs(2, 8, 900, 16, 9, pad_tail=100)
+    y = enc(pts.cuda())
+    so = O.clone_state(st, requires_grad=True)
+    yo = O.spatial_lidar_encoder(pts, so, "encoder.", (16, 16), False)
+    assert max_err(y, yo)[1] < TOL
+    with torch.no_grad():
+        assert torch.equal(enc(pts.cuda()).view(torch.int32), y.detach().view(torch.int32))    # inference path: same bits
+    up = torch.randn(yo.shape, generator=torch.Generator().manual_seed(8))
+    (y * up.cuda()).sum().backward()
+    (yo * up).sum().backward()
+    for name, p in enc.named_parameters():
+        assert max_err(p.grad, so[name].grad)[1] < 5 * TOL, name
+
+
 @pytest.mark.parametrize("fusion", ("concat", "minimal", "weighted"))
 def test_fusion_and_head_small(fusion):
     """Fusion block + head driven through the full-model oracle with tiny encoders' outputs replaced
