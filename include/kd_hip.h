@@ -119,7 +119,11 @@ int kd_lidar_l1_dgrad(const float* G, int64_t ldg, const float* Y1, int64_t ldy,
                       const float* ga, const float* msc, const float* msh, int mact, const float* Wt, float* G0,
                       int64_t ldg0, const float* pts, const float* w0, const float* b0, const float* sc0,
                       const float* sh0, const float* mean0, const float* invstd0, int act0, float* partial,
-                      int64_t M, int N1, int K0, void* stream);
+                      float* m1_out, void* m1_ws, size_t m1_ws_bytes, int64_t M, int N1, int K0, void* stream);
+/* m1_out (optional, [4][K0]) = sum_m G0[m][c] * pts[m][j]: the only way the layer-0 weight gradient depends on G0
+ * (dW0 = al0 * m1 + sum_m (be0*y0 + ga0) * pts, the second term from kd_lidar_l0_bwd with D = NULL).  With m1_out set,
+ * G0 may be NULL and the [points, K0] gradient is never written.  m1_ws: kd_lidar_l1_dgrad_ws_bytes. */
+size_t kd_lidar_l1_dgrad_ws_bytes(int64_t M, int K0);
 int kd_lidar_l1_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, int d_act, const float* al,
                       const float* be, const float* ga, const float* msc, const float* msh, const float* pts,
                       const float* w0, const float* b0, const float* sc0, const float* sh0, int act0, float* dW,

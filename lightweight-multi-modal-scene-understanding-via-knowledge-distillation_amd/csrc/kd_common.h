@@ -104,6 +104,7 @@ __device__ __forceinline__ float kd_wave_sum(float v) {
 
 // out[i] = sum_s slab[s][i], s in fixed order (deterministic); defined in kd_runtime.hip
 int kd_slab_reduce_launch(const float* slab, int nsplit, int64_t n, float* out, hipStream_t st);
+int kd_slab_reduce_tall_launch(float* slab, int rows, int64_t n, float* out, hipStream_t st);   // clobbers the slab
 
 // Generic "channel-group x row-slot" thread layout used by the HBM-bound NHWC kernels:
 // a thread owns 4 consecutive channels (one float4) and walks rows with a grid stride.

@@ -58,6 +58,9 @@ struct GemmArgs {
   // tmx / tshare = [cells][K] tables (cell maximum, dout / holders): G = (v > 0 && v == mx) ? share : 0 with
   // v = act(Y*p3 + p4), then the PRO2 formula al*G + be*Y + ga.
   const float* tmx; const float* tshare; const int* trows;
+  // EPI3 only: m1slab [rowblocks][4][N] receives per-block sums of G0[m][n] * point[m][j] (the part of the layer-0
+  // weight gradient that depends on this GEMM's result); with it set, C may be NULL and G0 is never stored.
+  float* m1slab;
 };
 
 // Tile shape: WM x WN waves of 64x64 each (WM*WN == 4): 128x128 for wide outputs, 256x64 when the
@@ -444,6 +447,9 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 4) ? 3
     eb = kd_ld4(g.l0b + colc);
   }
   float4 s1 = kd_zero4(), s2 = kd_zero4();
+  float4 m1[EPI == 3 ? 4 : 1];                         // EPI3: sum over rows of G0 * point coordinate j, per column
+#pragma unroll
+  for (int j = 0; j < (EPI == 3 ? 4 : 1); ++j) m1[j] = kd_zero4();
   constexpr int NI = (WM * 32) / RG;                   // rows per thread per half
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -514,6 +520,14 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 4) ? 3
           s2.y = fmaf(v.y, (x.y - emean.y) * einv.y, s2.y);
           s2.z = fmaf(v.z, (x.z - emean.z) * einv.z, s2.z);
           s2.w = fmaf(v.w, (x.w - emean.w) * einv.w, s2.w);
+          if constexpr (EPI == 3) {
+            const float pj[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              m1[j].x = fmaf(v.x, pj[j], m1[j].x); m1[j].y = fmaf(v.y, pj[j], m1[j].y);
+              m1[j].z = fmaf(v.z, pj[j], m1[j].z); m1[j].w = fmaf(v.w, pj[j], m1[j].w);
+            }
+          }
         }
       } else if (EPI == 5) {
         // inference finish: eval-mode BatchNorm + activation (+ residual) applied here, same operation order as the
@@ -526,7 +540,7 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 4) ? 3
           s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
         }
       }
-      if (ok) kd_st4(g.C + row * g.ldc + col, v);
+      if (EPI == 3 ? (ok && g.C != nullptr) : ok) kd_st4(g.C + row * g.ldc + col, v);
     }
   }
   if (EPI != 0 && EPI != 5) {
@@ -545,6 +559,23 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 4) ? 3
       const int64_t srow = (int64_t)rowblk * (BMt / 128);
       g.partial[(srow * 2 + st) * g.N + n0 + c] = s;
       if (BMt == 256 && (srow + 1) * 128 < g.M) g.partial[((srow + 1) * 2 + st) * g.N + n0 + c] = 0.f;
+    }
+    if constexpr (EPI == 3) {
+      if (g.m1slab) {                                // same two-level sum for the four G0*point moments: one slab row per TILE
+        kd_lds_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kd_st4(red + (rg * 4 + j) * BNt + c4e * 4, m1[j]);
+        kd_lds_barrier();
+        for (int i = tid; i < 4 * BNt; i += 256) {
+          const int j = i / BNt, c = i % BNt;
+          if (n0 + c < g.N) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < RG; ++k) s += red[(k * 4 + j) * BNt + c];
+            g.m1slab[((int64_t)rowblk * 4 + j) * g.N + n0 + c] = s;
+          }
+        }
+      }
     }
   }
   KD_PH(5);                            // epilogue
@@ -998,20 +1029,32 @@ int kd_lidar_l1_fwd(const float* pts, const float* w0, const float* b0, const fl
 
 // data gradient: G0[M,K0] = (dy1_eff[M,N1] . W1) * act0'(bn0(l0(pts))) with the BN0-backward sums in `partial`;
 // dy1_eff = al*(G*mask(Y1*msc+msh)) + be*Y1 + ga; Wt = W1 as stored ([N1][K0]) transposed by the caller ([K0][N1]).
+size_t kd_lidar_l1_dgrad_ws_bytes(int64_t M, int K0) { return (size_t)((M + 127) / 128) * 4 * K0 * sizeof(float); }
+
+// m1_out (optional, [4][K0]) = sum_m G0[m][:] * pts[m][j]: with it (and its workspace m1_ws of
+// kd_lidar_l1_dgrad_ws_bytes) the layer-0 weight gradient needs G0 only through these moments, and G0 may be NULL.
 int kd_lidar_l1_dgrad(const float* G, int64_t ldg, const float* Y1, int64_t ldy, const float* al, const float* be,
                       const float* ga, const float* msc, const float* msh, int mact, const float* Wt, float* G0,
                       int64_t ldg0, const float* pts, const float* w0, const float* b0, const float* sc0,
                       const float* sh0, const float* mean0, const float* invstd0, int act0, float* partial,
-                      int64_t M, int N1, int K0, void* stream) {
-  KD_REQUIRE(G && Y1 && al && be && ga && Wt && G0 && pts && w0 && b0 && sc0 && sh0 && mean0 && invstd0 && partial && M > 0,
+                      float* m1_out, void* m1_ws, size_t m1_ws_bytes, int64_t M, int N1, int K0, void* stream) {
+  KD_REQUIRE(G && Y1 && al && be && ga && Wt && (G0 || m1_out) && pts && w0 && b0 && sc0 && sh0 && mean0 && invstd0 && partial && M > 0,
              KD_ERR_ARG, "kd_lidar_l1_dgrad: bad args");
+  KD_REQUIRE(!m1_out || (m1_ws && m1_ws_bytes >= kd_lidar_l1_dgrad_ws_bytes(M, K0)), KD_ERR_WORKSPACE,
+             "kd_lidar_l1_dgrad: moment workspace missing or too small");
   KD_REQUIRE(mact == KD_ACT_NONE || (msc && msh), KD_ERR_ARG, "kd_lidar_l1_dgrad: mask needs sc/sh");
   KD_REQUIRE(M < (int64_t)1 << 31 && N1 % 4 == 0 && K0 % 4 == 0 && ldg % 4 == 0 && ldy % 4 == 0 && ldg0 % 4 == 0, KD_ERR_SHAPE,
              "kd_lidar_l1_dgrad: channel counts and strides must be multiples of 4");
   if (!msc) { msc = al; msh = al; }
   GemmArgs g{G, ldg, Y1, ldy, al, be, ga, msc, msh, 2, mact, Wt, nullptr, G0, ldg0, nullptr, 0,
-             pts, 4, sc0, sh0, mean0, invstd0, act0, partial, (int)M, N1, K0, nullptr, w0, b0};
-  return gemm_launch(g, 2, 3, (hipStream_t)stream);
+             pts, 4, sc0, sh0, mean0, invstd0, act0, partial, (int)M, N1, K0, nullptr, w0, b0,
+             nullptr, nullptr, nullptr, m1_out ? (float*)m1_ws : nullptr};
+  const int rc = gemm_launch(g, 2, 3, (hipStream_t)stream);
+  if (rc || !m1_out) return rc;
+  // one slab row per output tile: 256 rows when the output is at most 64 wide (see gemm_launch), else 128
+  const bool tall = ((K0 - 1) % 128) < 64;
+  const int nrb = (int)(tall ? (M + 255) / 256 : (M + 127) / 128);
+  return kd_slab_reduce_tall_launch((float*)m1_ws, nrb, (int64_t)4 * K0, m1_out, (hipStream_t)stream);
 }
 
 // weight gradient dW1[N,K] = dy1_eff[M,N]^T . act0(bn0(l0(pts)))[M,K]

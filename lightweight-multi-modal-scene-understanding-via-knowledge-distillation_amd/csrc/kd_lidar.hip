@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256) void lidar_l0_bwd_kernel(L0BwdArgs a) {
     }
     for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < a.P; p += (int64_t)gridDim.x * a.slots) {
       const float4 pt = kd_ld4(a.pts + p * 4);
-      const float4 d = kd_ld4(a.D + p * a.C + c0), y = a.Y ? kd_ld4(a.Y + p * a.C + c0) : kd_l0_raw4(pt, wr, bias);
+      // D == NULL: the gradient-dependent part comes from kd_lidar_l1_dgrad's moments; this pass adds sum (be*y + ga) * pt
+      const float4 d = a.D ? kd_ld4(a.D + p * a.C + c0) : kd_zero4();
+      const float4 y = a.Y ? kd_ld4(a.Y + p * a.C + c0) : kd_l0_raw4(pt, wr, bias);
       float4 g;
       g.x = kd_bwd_operand(d.x, y.x, al.x, be.x, ga.x, 0.f, 0.f, KD_ACT_NONE);
       g.y = kd_bwd_operand(d.y, y.y, al.y, be.y, ga.y, 0.f, 0.f, KD_ACT_NONE);
@@ -243,7 +245,7 @@ size_t kd_lidar_l0_bwd_ws_bytes(int64_t P, int C) { return (size_t)kd_cg_layout(
 int kd_lidar_l0_bwd(const float* D, const float* Y, const float* w, const float* b, const float* al, const float* be,
                     const float* ga, const float* pts, float* dwb, int64_t P, int C, void* ws, size_t ws_bytes,
                     void* stream) {
-  KD_REQUIRE(D && (Y || w) && al && be && ga && pts && dwb && ws && P > 0 && C % 4 == 0, KD_ERR_ARG, "kd_lidar_l0_bwd: bad args");
+  KD_REQUIRE((D || !Y) && (Y || w) && al && be && ga && pts && dwb && ws && P > 0 && C % 4 == 0, KD_ERR_ARG, "kd_lidar_l0_bwd: bad args");
   const KdCgLayout l = kd_cg_layout(P, C);
   KD_REQUIRE(ws_bytes >= (size_t)l.grid * C * 5 * sizeof(float), KD_ERR_WORKSPACE, "kd_lidar_l0_bwd: workspace too small");
   L0BwdArgs a{D, Y, al, be, ga, pts, (float*)ws, P, C, l.groups, l.slots, w, b};

@@ -40,7 +40,43 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
     out[i] = t;
   }
 }
+// Tall slabs (one row per GEMM tile: tens of thousands of rows): groups of ~sqrt(rows) rows are first summed, in
+// double, into the group's first row -- grid (ceil(n/64), groups), block (64, 4) -- so the final pass walks
+// rows/group rows instead of serialising the whole column in a handful of workgroups.  The slab is scratch.
+__global__ void slab_group_sum_kernel(float* slab, int rows, int64_t n, int group) {
+  __shared__ double sm[4][64];
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int r0 = blockIdx.y * group;
+  const int r1 = r0 + group < rows ? r0 + group : rows;
+  double a = 0.0;
+  if (i < n)
+    for (int r = r0 + threadIdx.y; r < r1; r += 4) a += (double)slab[(int64_t)r * n + i];
+  sm[threadIdx.y][threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.y == 0 && i < n)
+    slab[(int64_t)r0 * n + i] = (float)(sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+__global__ void slab_strided_sum_kernel(const float* __restrict__ slab, int ngroups, int group, int64_t n, float* __restrict__ out) {
+  __shared__ double sm[4][64];
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  double a = 0.0;
+  if (i < n)
+    for (int k = threadIdx.y; k < ngroups; k += 4) a += (double)slab[(int64_t)k * group * n + i];
+  sm[threadIdx.y][threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.y == 0 && i < n) out[i] = (float)(sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
 }  // namespace
+
+int kd_slab_reduce_tall_launch(float* slab, int rows, int64_t n, float* out, hipStream_t st) {
+  int group = 1;
+  while ((int64_t)group * group < rows) ++group;
+  const int ngroups = (rows + group - 1) / group;
+  const unsigned nx = (unsigned)((n + 63) / 64);
+  hipLaunchKernelGGL(slab_group_sum_kernel, dim3(nx, ngroups), dim3(64, 4), 0, st, slab, rows, n, group);
+  hipLaunchKernelGGL(slab_strided_sum_kernel, dim3(nx), dim3(64, 4), 0, st, slab, ngroups, group, n, out);
+  return kd_check_launch("kd_slab_reduce_tall");
+}
 
 int kd_slab_reduce_launch(const float* slab, int nsplit, int64_t n, float* out, hipStream_t st) {
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64, 16), 0, st, slab, nsplit, n, out);

@@ -191,13 +191,19 @@ def l2_fwd_scatter(op: Operand, W, bias, bnc2: BNC, act2, cell_idx, grid, ncells
     _prof_end(e0, "pw_gemm", 2.0 * M * N * K, 4.0 * (M * K + M * 1 + N * K), m_dev, M)     # reads A + cell index; no output tensor
 
 
-def l1_dgrad(t, y, Wt, gin, *, op: Operand, al, be, ga, msc, msh, mact, partial):
+def l1_dgrad(t, y, Wt, gin, *, op: Operand, al, be, ga, msc, msh, mact, partial, moments=None):
+    """moments ([4, K0] tensor, optional): receives sum_m G0 * point; with it `gin` may be None (G0 is never written)."""
     pts, w0, b0 = op.virt
     M, N1, K0 = pts.shape[0], y.shape[1], w0.shape[0]
+    nbytes, ws = 0, None
+    if moments is not None:
+        nbytes = lib.kd_lidar_l1_dgrad_ws_bytes(M, K0)
+        ws = workspace(nbytes, y.device)
     e0 = _prof_begin()
-    lib.call("kd_lidar_l1_dgrad", P(t), ld(t), P(y), ld(y), P(al), P(be), P(ga), P(msc), P(msh), mact, P(Wt), P(gin), ld(gin),
-             P(pts), P(w0), P(b0), P(op.sc), P(op.sh), P(op.bnc.mean), P(op.bnc.invstd), op.act, P(partial), M, N1, K0, stream())
-    _prof_end(e0, "pw_gemm", 2.0 * M * N1 * K0, 4.0 * (2 * M * N1 + M * K0 + M * 4 + N1 * K0), None, M)
+    lib.call("kd_lidar_l1_dgrad", P(t), ld(t), P(y), ld(y), P(al), P(be), P(ga), P(msc), P(msh), mact, P(Wt), P(gin),
+             ld(gin) if gin is not None else K0, P(pts), P(w0), P(b0), P(op.sc), P(op.sh), P(op.bnc.mean), P(op.bnc.invstd),
+             op.act, P(partial), P(moments), P(ws), nbytes, M, N1, K0, stream())
+    _prof_end(e0, "pw_gemm", 2.0 * M * N1 * K0, 4.0 * (2 * M * N1 + (M * K0 if gin is not None else 0) + M * 4 + N1 * K0), None, M)
 
 
 def l2_dgrad(tables, out_op: Operand, Wt, gin, *, inp: Operand, al, be, ga, partial):

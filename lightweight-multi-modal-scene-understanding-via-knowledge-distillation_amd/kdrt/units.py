@@ -246,11 +246,18 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
             if inp.virt is not None:
                 if addend is not None:
                     raise KDError("addend on a virtual LiDAR layer-0 input is not supported")
-                gin = torch.empty(M, K, device=dev, dtype=torch.float32)
                 rows_in = lib.kd_pwconv_stat_rows(M)
                 part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
-                ops.l1_dgrad(t, y, Wt, gin, op=inp, al=al, be=be, ga=ga, msc=msc, msh=msh, mact=mact, partial=part_in)
-                g_in = ("G", gin, part_in, rows_in)
+                if _L0_MOMENTS:
+                    # layer 0's weight gradient is linear in G0: the GEMM epilogue leaves sum G0 * point and G0 is never written
+                    m1 = torch.empty(4, K, device=dev, dtype=torch.float32)
+                    ops.l1_dgrad(t, y, Wt, None, op=inp, al=al, be=be, ga=ga, msc=msc, msh=msh, mact=mact, partial=part_in,
+                                 moments=m1)
+                    g_in = ("GM", m1, part_in, rows_in)
+                else:
+                    gin = torch.empty(M, K, device=dev, dtype=torch.float32)
+                    ops.l1_dgrad(t, y, Wt, gin, op=inp, al=al, be=be, ga=ga, msc=msc, msh=msh, mact=mact, partial=part_in)
+                    g_in = ("G", gin, part_in, rows_in)
             elif tables:
                 gin = torch.empty(M, K, device=dev, dtype=torch.float32)
                 rows_in = lib.kd_pwconv_stat_rows(M)
@@ -310,14 +317,20 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
         ops.pw_wgrad(t, col, dWp, M=M, N=C, K=Kp, X=y, d_mode=2, d_act=mact, al=al, be=be, ga=ga, msc=msc, msh=msh)
         grads = [gradsink.deliver(rec.w, dWp[:, : Cin * 9])]
     elif kind == "l0":
-        if g[0] != "G":
+        if g[0] not in ("G", "GM"):
             raise KDError("LiDAR layer-0 backward expects a masked gradient")
         pts = rec.inp
         nbytes = lib.kd_lidar_l0_bwd_ws_bytes(M, C)
         ws = ops.workspace(nbytes, dev)
         dwb = torch.empty(C * 5, device=dev, dtype=torch.float32)
-        lib.call("kd_lidar_l0_bwd", P(t), P(y), P(rec.w), P(rec.b), P(al), P(be), P(ga), P(pts), P(dwb), M, C, P(ws), nbytes,
-                 stream())
+        moments = g[0] == "GM"
+        # dW0 = sum_p (al*G0 + be*y0 + ga) * pt.  "GM": t = sum_p G0 * pt ([4, C], from the layer-1 dgrad epilogue); this
+        # pass then runs without G0 (D = NULL: the be*y0 + ga part, y0 recomputed from the point) and al * t is added.
+        lib.call("kd_lidar_l0_bwd", None if moments else P(t), P(y), P(rec.w), P(rec.b), P(al), P(be), P(ga), P(pts), P(dwb), M, C,
+                 P(ws), nbytes, stream())
+        if moments:
+            dwb[: C * 4].view(C, 4).addcmul_(al.view(C, 1), t.t())
+            dwb[C * 4:].addcmul_(al, dbeta)                      # sum_p G0 == dbeta of this BatchNorm
         grads = [gradsink.deliver(rec.w, dwb[: C * 4]), gradsink.deliver(rec.b, dwb[C * 4:])]
     elif kind == "ct":
         inp = rec.inp
@@ -765,6 +778,8 @@ _SCATTER_MODE = os.environ.get("KD_SCATTER", "sorted")
 # with sorted points: hand the scatter-max gradient to the last layer's backward GEMMs as per-cell tables (default) or
 # as the materialised [points, C] tensor ("0": A/B and tests)
 _SCATTER_TABLES = os.environ.get("KD_SCATTER_TABLES", "1") != "0"
+# layer 0's gradient through moments of G0 accumulated in the layer-1 dgrad epilogue (default) or through the stored G0
+_L0_MOMENTS = os.environ.get("KD_L0_MOMENTS", "1") != "0"
 
 
 _sort_cache: dict = {}
