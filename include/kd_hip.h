@@ -168,9 +168,11 @@ int kd_lidar_sort_points(const float* pts, int B, int64_t N, int H, int W, float
  * the two GEMMs rebuild G[m][c] = (rows[m] >= 0 && v > 0 && v == grid[rows[m]][c]) ? share[rows[m]][c] : 0 on load
  * (v = act2(Y2*sc2 + sh2)) -- bit-identical to kd_lidar_seg_max_bwd + kd_pwconv_gemm(pro 2, epi 2) / kd_pwconv_wgrad
  * (d_mode 2), minus 2.5 passes over a [points, C] tensor. */
+int64_t kd_lidar_seg_share_stat_rows(int64_t ncells, int64_t P);
 int kd_lidar_seg_share_bwd(const float* y, const float* sc, const float* sh, int act, const float* grid,
                            const float* dout, const float* mean, const float* invstd, const int* seg_start,
-                           float* share, float* partial, int64_t ncells, int C, void* stream);
+                           const int* row_sorted, float* share, float* cnt_ws, float* partial, int64_t P,
+                           int64_t ncells, int C, void* stream);
 int kd_lidar_l2_dgrad(const float* Y2, int64_t ldy2, const int* rows, const float* grid, const float* share,
                       const float* al, const float* be, const float* ga, const float* sc2, const float* sh2, int act2,
                       const float* Wt, float* G1, int64_t ldg1, const float* Y1, int64_t ldy1, const float* sc1,
@@ -182,8 +184,11 @@ int kd_lidar_l2_wgrad(const float* Y2, int64_t ldy2, const int* rows, const floa
                       int64_t M, int N2, int K1, void* ws, size_t ws_bytes, void* stream);
 int kd_lidar_gather_sorted(const float* pts, const int* perm, const int* row_of_point, const int* nvalid_dev,
                            float* out_pts, int* out_row, int64_t P, void* stream);
+/* row_sorted (optional, rows sorted by kd_lidar_sort_points, perm == NULL): grid rows holding more than 256 points are
+ * then processed 64 points per wave, so a scene concentrated in a few cells costs what a uniform one costs. */
 int kd_lidar_seg_max_fwd(const float* y, const float* sc, const float* sh, int act, const int* seg_start,
-                         const int* perm, float* grid, int64_t ncells, int C, void* stream);
+                         const int* perm, const int* row_sorted, float* grid, int64_t P, int64_t ncells, int C,
+                         void* stream);
 int64_t kd_lidar_seg_stat_rows(int64_t ncells);
 int kd_lidar_seg_max_bwd(const float* y, const float* sc, const float* sh, int act, const float* grid,
                          const float* dout, const float* mean, const float* invstd, const int* seg_start,

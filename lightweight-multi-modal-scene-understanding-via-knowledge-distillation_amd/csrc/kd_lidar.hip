@@ -585,7 +585,13 @@ struct SegArgs {
   const int* start; const int* perm;                                  // [ncells + 1], [P]
   float* grid; const float* dout; const float* mean; const float* invstd;
   float* G; float* partial; int64_t ncells; int C;
+  // Load balance: a grid row with more than `long_len` points (0 = no limit) is left to the chunked kernels below -- one
+  // wave per 64 consecutive sorted rows -- so a scene that piles thousands of points into a few cells (a real LiDAR
+  // sweep does, around the sensor) costs what a uniform one costs.  rowid [P]: grid row of each sorted point;
+  // cnt [ncells, C]: holder counts of the long rows (float, exact); prow0: first slab row of the chunked kernel.
+  int long_len; const int* rowid; float* cnt; int prow0;
 };
+constexpr int SEG_LONG = 256;
 
 template <int VEC> struct SegVec;
 template <> struct SegVec<1> { typedef float type; };
@@ -613,7 +619,8 @@ __global__ __launch_bounds__(256) void seg_max_fwd_kernel(SegArgs a) {
   const int64_t nw = (int64_t)gridDim.x * 4;
   for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < a.ncells; row += nw) {
     const int s = __builtin_amdgcn_readfirstlane(a.start[row]);
-    const int e = __builtin_amdgcn_readfirstlane(a.start[row + 1]);
+    int e = __builtin_amdgcn_readfirstlane(a.start[row + 1]);
+    if (a.long_len > 0 && e - s > a.long_len) e = s;     // long row: zero here, maxima from seg_long_fwd_kernel's atomics
     float m[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) m[j] = 0.f;
@@ -666,6 +673,13 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
     const int s = __builtin_amdgcn_readfirstlane(a.start[row]);
     const int e = __builtin_amdgcn_readfirstlane(a.start[row + 1]);
     if (s == e) continue;
+    if (TABLE && a.long_len > 0 && e - s > a.long_len) {   // long row: counted and shared out by the chunked kernels
+      float z[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) z[j] = 0.f;
+      seg_st<VEC>(a.cnt + row * a.C + c0, z);
+      continue;
+    }
     float mx[VEC], d[VEC];
     seg_ld<VEC>(mx, a.grid + row * a.C + c0);
     seg_ld<VEC>(d, a.dout + row * a.C + c0);
@@ -753,6 +767,108 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(SegArgs a) {
     a.partial[((int64_t)blockIdx.x * 2 + st) * a.C + c] = red[0][st][c] + red[1][st][c] + red[2][st][c] + red[3][st][c];
   }
 }
+
+// ---- chunked kernels for the long rows: wave w owns sorted rows [64w, 64w + 64) -----------------------------------
+// A long row (> SEG_LONG >= 64 points) that meets a chunk contains the chunk's first or its last point, so the two
+// lookups below reject every chunk of an ordinary scene.  MODE 0: forward maxima (atomicMax on the zeroed grid row);
+// MODE 1: holder counts (float atomicAdd of small integers: exact, order-independent); MODE 2: share = dout / count
+// (stored once, by the chunk that holds the row's first point) and the BatchNorm-backward sums of the chunk's points.
+template <int VEC, int MODE>
+__global__ __launch_bounds__(256) void seg_long_kernel(SegArgs a) {
+  __shared__ float red[4][2][64 * VEC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = lane * VEC;
+  float sc[VEC], sh[VEC], mu[VEC], inv[VEC], s1[VEC], s2[VEC];
+  seg_ld<VEC>(sc, a.sc + c0);
+  seg_ld<VEC>(sh, a.sh + c0);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = 0.f; inv[j] = 0.f; }
+  if (MODE == 2) { seg_ld<VEC>(mu, a.mean + c0); seg_ld<VEC>(inv, a.invstd + c0); }
+  const int nvalid = __builtin_amdgcn_readfirstlane(a.start[a.ncells]);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t w = (int64_t)blockIdx.x * 4 + wave; w * 64 < nvalid; w += nw) {
+    const int i0 = (int)(w * 64), i1 = i0 + 64 < nvalid ? i0 + 64 : nvalid;
+    const int cf = __builtin_amdgcn_readfirstlane(a.rowid[i0]), cl = __builtin_amdgcn_readfirstlane(a.rowid[i1 - 1]);
+    const bool lf = a.start[cf + 1] - a.start[cf] > a.long_len, ll = a.start[cl + 1] - a.start[cl] > a.long_len;
+    if (!lf && !ll) continue;
+    int i = i0;
+    while (i < i1) {
+      const int cell = __builtin_amdgcn_readfirstlane(a.rowid[i]);
+      const int cs = __builtin_amdgcn_readfirstlane(a.start[cell]), ce = __builtin_amdgcn_readfirstlane(a.start[cell + 1]);
+      const int rend = ce < i1 ? ce : i1;                 // this chunk's run of `cell`: [i, rend)
+      if (ce - cs <= a.long_len) { i = rend; continue; }
+      float acc[VEC], mx[VEC], share[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { acc[j] = 0.f; mx[j] = 0.f; share[j] = 0.f; }
+      if (MODE >= 1) seg_ld<VEC>(mx, a.grid + (int64_t)cell * a.C + c0);
+      if (MODE == 2) {
+        float d[VEC], n[VEC];
+        seg_ld<VEC>(d, a.dout + (int64_t)cell * a.C + c0);
+        seg_ld<VEC>(n, a.cnt + (int64_t)cell * a.C + c0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) share[j] = n[j] > 0.f ? d[j] / n[j] : 0.f;
+        if (i == cs) seg_st<VEC>(a.G + (int64_t)cell * a.C + c0, share);
+      }
+      int k = i;
+      for (; k + 4 <= rend; k += 4) {
+        float r[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) seg_ld<VEC>(r[u], a.y + (int64_t)(k + u) * a.C + c0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const float v = kd_act(kd_affine(r[u][j], sc[j], sh[j]), a.act);
+            if (MODE == 0) acc[j] = v > acc[j] ? v : acc[j];
+            if (MODE == 1) acc[j] += (v > 0.f && v == mx[j]) ? 1.f : 0.f;
+            if (MODE == 2) {
+              const float g = (v > 0.f && v == mx[j]) ? share[j] : 0.f;
+              s1[j] += g;
+              s2[j] = fmaf(g, (r[u][j] - mu[j]) * inv[j], s2[j]);
+            }
+          }
+      }
+      for (; k < rend; ++k) {
+        float r[VEC];
+        seg_ld<VEC>(r, a.y + (int64_t)k * a.C + c0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float v = kd_act(kd_affine(r[j], sc[j], sh[j]), a.act);
+          if (MODE == 0) acc[j] = v > acc[j] ? v : acc[j];
+          if (MODE == 1) acc[j] += (v > 0.f && v == mx[j]) ? 1.f : 0.f;
+          if (MODE == 2) {
+            const float g = (v > 0.f && v == mx[j]) ? share[j] : 0.f;
+            s1[j] += g;
+            s2[j] = fmaf(g, (r[j] - mu[j]) * inv[j], s2[j]);
+          }
+        }
+      }
+      if (MODE == 0) {
+        unsigned* dst = reinterpret_cast<unsigned*>(a.grid + (int64_t)cell * a.C + c0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (acc[j] > 0.f) atomicMax(dst + j, __float_as_uint(acc[j]));
+      }
+      if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (acc[j] > 0.f) atomicAdd(a.cnt + (int64_t)cell * a.C + c0 + j, acc[j]);
+      }
+      i = rend;
+    }
+  }
+  if (MODE == 2) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[wave][0][c0 + j] = s1[j]; red[wave][1][c0 + j] = s2[j]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) {
+      const int st = i / a.C, c = i % a.C;
+      a.partial[((int64_t)(a.prow0 + blockIdx.x) * 2 + st) * a.C + c] = red[0][st][c] + red[1][st][c] + red[2][st][c] + red[3][st][c];
+    }
+  }
+}
+
+inline int seg_long_grid(int64_t P) { const int64_t b = (P + 255) / 256; return (int)(b < 1024 ? b : 1024); }
 
 // rows of G that belong to out-of-range points get no gradient: they are not in any segment
 // (a 256-thread block sweeps 16 * (1024 / C) consecutive points: one wave per handful of stores would be launch-bound)
@@ -865,12 +981,16 @@ int kd_lidar_gather_sorted(const float* pts, const int* perm, const int* row_of_
 }
 
 // grid[ncells, C] = per-row max of act(y*sc+sh) over the row's points (0 for empty rows); every row is written.
+// row_sorted (optional, only without perm): grid row of every sorted point; with it, rows holding more than 256 points
+// are processed 64 points per wave (load balance on concentrated scenes); P = number of points (bounds the launch).
 int kd_lidar_seg_max_fwd(const float* y, const float* sc, const float* sh, int act, const int* seg_start, const int* perm,
-                         float* grid, int64_t ncells, int C, void* stream) {
+                         const int* row_sorted, float* grid, int64_t P, int64_t ncells, int C, void* stream) {
   KD_REQUIRE(y && sc && sh && seg_start && grid && ncells > 0, KD_ERR_ARG, "kd_lidar_seg_max_fwd: bad args");
   KD_REQUIRE(C == 64 || C == 128 || C == 256, KD_ERR_SHAPE, "kd_lidar_seg_max_fwd: C must be 64, 128 or 256 (got %d)", C);
   KD_REQUIRE(act == KD_ACT_RELU || act == KD_ACT_RELU6, KD_ERR_ARG, "kd_lidar_seg_max_fwd: needs a non-negative activation");
-  SegArgs a{y, sc, sh, act, seg_start, perm, grid, nullptr, nullptr, nullptr, nullptr, nullptr, ncells, C};
+  const bool chunked = row_sorted != nullptr && perm == nullptr && P > 0;
+  SegArgs a{y, sc, sh, act, seg_start, perm, grid, nullptr, nullptr, nullptr, nullptr, nullptr, ncells, C,
+            chunked ? SEG_LONG : 0, row_sorted, nullptr, 0};
   const dim3 gr(seg_grid(ncells)), bl(256);
   hipStream_t st = (hipStream_t)stream;
 #define KD_SEG_LAUNCH(kern)                                                                          \
@@ -880,6 +1000,12 @@ int kd_lidar_seg_max_fwd(const float* y, const float* sc, const float* sh, int a
     else { if (perm) hipLaunchKernelGGL((kern<4, true>), gr, bl, 0, st, a); else hipLaunchKernelGGL((kern<4, false>), gr, bl, 0, st, a); } \
   } while (0)
   KD_SEG_LAUNCH(seg_max_fwd_kernel);
+  if (chunked) {
+    const dim3 gl(seg_long_grid(P));
+    if (C == 64) hipLaunchKernelGGL((seg_long_kernel<1, 0>), gl, bl, 0, st, a);
+    else if (C == 128) hipLaunchKernelGGL((seg_long_kernel<2, 0>), gl, bl, 0, st, a);
+    else hipLaunchKernelGGL((seg_long_kernel<4, 0>), gl, bl, 0, st, a);
+  }
   return kd_check_launch("kd_lidar_seg_max_fwd");
 }
 
@@ -892,7 +1018,7 @@ int kd_lidar_seg_max_bwd(const float* y, const float* sc, const float* sh, int a
   KD_REQUIRE(y && sc && sh && grid && dout && mean && invstd && seg_start && row_of_point && G && partial && P > 0 && ncells > 0,
              KD_ERR_ARG, "kd_lidar_seg_max_bwd: bad args");
   KD_REQUIRE(C == 64 || C == 128 || C == 256, KD_ERR_SHAPE, "kd_lidar_seg_max_bwd: C must be 64, 128 or 256 (got %d)", C);
-  SegArgs a{y, sc, sh, act, seg_start, perm, const_cast<float*>(grid), dout, mean, invstd, G, partial, ncells, C};
+  SegArgs a{y, sc, sh, act, seg_start, perm, const_cast<float*>(grid), dout, mean, invstd, G, partial, ncells, C, 0, nullptr, nullptr, 0};
   const dim3 gr(seg_grid(ncells)), bl(256);
   hipStream_t st = (hipStream_t)stream;
   const int c4 = C / 4;
@@ -906,18 +1032,33 @@ int kd_lidar_seg_max_bwd(const float* y, const float* sc, const float* sh, int a
 // Table form of kd_lidar_seg_max_bwd for rows sorted by cell (kd_lidar_sort_points; row r of `y` belongs to grid row
 // g iff seg_start[g] <= r < seg_start[g+1]): share[ncells, C] = dout / holders (rows of empty cells are not written and
 // never read), partial as in kd_lidar_seg_max_bwd.  G itself is rebuilt by kd_lidar_l2_dgrad / kd_lidar_l2_wgrad.
+// partial has kd_lidar_seg_share_stat_rows(ncells, P) rows; cnt_ws [ncells, C] floats is scratch (holder counts of the
+// rows with more than 256 points, which the chunked kernels process 64 points per wave).
+int64_t kd_lidar_seg_share_stat_rows(int64_t ncells, int64_t P) { return seg_grid(ncells) + seg_long_grid(P); }
+
 int kd_lidar_seg_share_bwd(const float* y, const float* sc, const float* sh, int act, const float* grid, const float* dout,
-                           const float* mean, const float* invstd, const int* seg_start, float* share, float* partial,
-                           int64_t ncells, int C, void* stream) {
-  KD_REQUIRE(y && sc && sh && grid && dout && mean && invstd && seg_start && share && partial && ncells > 0, KD_ERR_ARG,
-             "kd_lidar_seg_share_bwd: bad args");
+                           const float* mean, const float* invstd, const int* seg_start, const int* row_sorted, float* share,
+                           float* cnt_ws, float* partial, int64_t P, int64_t ncells, int C, void* stream) {
+  KD_REQUIRE(y && sc && sh && grid && dout && mean && invstd && seg_start && row_sorted && share && cnt_ws && partial && ncells > 0 && P > 0,
+             KD_ERR_ARG, "kd_lidar_seg_share_bwd: bad args");
   KD_REQUIRE(C == 64 || C == 128 || C == 256, KD_ERR_SHAPE, "kd_lidar_seg_share_bwd: C must be 64, 128 or 256 (got %d)", C);
-  SegArgs a{y, sc, sh, act, seg_start, nullptr, const_cast<float*>(grid), dout, mean, invstd, share, partial, ncells, C};
-  const dim3 gr(seg_grid(ncells)), bl(256);
+  SegArgs a{y, sc, sh, act, seg_start, nullptr, const_cast<float*>(grid), dout, mean, invstd, share, partial, ncells, C,
+            SEG_LONG, row_sorted, cnt_ws, seg_grid(ncells)};
+  const dim3 gr(seg_grid(ncells)), gl(seg_long_grid(P)), bl(256);
   hipStream_t st = (hipStream_t)stream;
-  if (C == 64) hipLaunchKernelGGL((seg_max_bwd_kernel<1, false, true>), gr, bl, 0, st, a);
-  else if (C == 128) hipLaunchKernelGGL((seg_max_bwd_kernel<2, false, true>), gr, bl, 0, st, a);
-  else hipLaunchKernelGGL((seg_max_bwd_kernel<4, false, true>), gr, bl, 0, st, a);
+  if (C == 64) {
+    hipLaunchKernelGGL((seg_max_bwd_kernel<1, false, true>), gr, bl, 0, st, a);
+    hipLaunchKernelGGL((seg_long_kernel<1, 1>), gl, bl, 0, st, a);
+    hipLaunchKernelGGL((seg_long_kernel<1, 2>), gl, bl, 0, st, a);
+  } else if (C == 128) {
+    hipLaunchKernelGGL((seg_max_bwd_kernel<2, false, true>), gr, bl, 0, st, a);
+    hipLaunchKernelGGL((seg_long_kernel<2, 1>), gl, bl, 0, st, a);
+    hipLaunchKernelGGL((seg_long_kernel<2, 2>), gl, bl, 0, st, a);
+  } else {
+    hipLaunchKernelGGL((seg_max_bwd_kernel<4, false, true>), gr, bl, 0, st, a);
+    hipLaunchKernelGGL((seg_long_kernel<4, 1>), gl, bl, 0, st, a);
+    hipLaunchKernelGGL((seg_long_kernel<4, 2>), gl, bl, 0, st, a);
+  }
   return kd_check_launch("kd_lidar_seg_share_bwd");
 }
 

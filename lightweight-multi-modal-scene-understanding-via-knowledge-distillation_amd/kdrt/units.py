@@ -920,8 +920,8 @@ class LidarFn(torch.autograd.Function):
         ctx.seg = seg
         if seg is not None:
             # forward max and backward tie split over the segments: atomic-free
-            lib.call("kd_lidar_seg_max_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(seg[1]), P(seg[2]), P(grid),
-                     B * H * W, C, stream())
+            lib.call("kd_lidar_seg_max_fwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(seg[1]), P(seg[2]),
+                     P(seg[0]) if seg[2] is None else None, P(grid), B * N, B * H * W, C, stream())
         else:
             lib.call("kd_lidar_scatter_max_fwd", P(pts), P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(grid), B, N, C, H, W,
                      float(rng[0]), float(rng[1]), float(rng[2]), float(rng[3]), stream())
@@ -940,11 +940,12 @@ class LidarFn(torch.autograd.Function):
                 and last.inp.virt is None and last.inp.bnc is not None):
             # rows sorted by cell: the [points, C] gradient is never written -- per-cell tables instead
             row_sorted, seg_start, _ = ctx.seg
-            rows = lib.kd_lidar_seg_stat_rows(B * H * W)
+            rows = lib.kd_lidar_seg_share_stat_rows(B * H * W, Pn)
             partial = torch.empty(rows * 2 * C, device=dev, dtype=torch.float32)
             share = torch.empty(B * H * W, C, device=dev, dtype=torch.float32)
+            cnt_ws = torch.empty(B * H * W, C, device=dev, dtype=torch.float32)
             lib.call("kd_lidar_seg_share_bwd", P(cur.raw), P(cur.sc), P(cur.sh), cur.act, P(ctx.grid), P(dm), P(cur.bnc.mean),
-                     P(cur.bnc.invstd), P(seg_start), P(share), P(partial), B * H * W, C, stream())
+                     P(cur.bnc.invstd), P(seg_start), P(row_sorted), P(share), P(cnt_ws), P(partial), Pn, B * H * W, C, stream())
             grads, _ = chain_backward(ctx.recs, ("GS", (row_sorted, ctx.grid, share), partial, rows), need_input_grad=False)
             return (None, None, None, None, None, *grads)
         G = torch.empty(Pn, C, device=dev, dtype=torch.float32)

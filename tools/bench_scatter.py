@@ -1,5 +1,5 @@
 """Times the training scatter-max entry points (atomic pair vs cell-sorted pair) at bench size.
-usage: python tools/bench_scatter.py [B] [N]"""
+usage: python tools/bench_scatter.py [B] [N] [sigma_m]"""
 import ctypes
 import os
 import sys
@@ -12,12 +12,13 @@ from kdrt.lib import lib  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 80000
+SIGMA = float(sys.argv[3]) if len(sys.argv) > 3 else 40.0      # metres; small values pile the points into few cells
 H = W = 64
 C = 128
 RNG = (-50.0, 50.0, -50.0, 50.0)
 P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
 g = torch.Generator().manual_seed(0)
-pts = (torch.randn(B * N, 4, generator=g) * torch.tensor([40.0, 40.0, 2.0, 1.0])).cuda()
+pts = (torch.randn(B * N, 4, generator=g) * torch.tensor([SIGMA, SIGMA, 2.0, 1.0])).cuda()
 y = torch.randn(B * N, C, device="cuda")
 sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.2
 mean, invstd = torch.randn(C, device="cuda") * 0.1, torch.rand(C, device="cuda") + 0.5
@@ -48,15 +49,19 @@ timed("atomic fwd", lambda: lib.call("kd_lidar_scatter_max_fwd", P(pts), P(y), P
 timed("atomic bwd", lambda: lib.call("kd_lidar_scatter_max_bwd", P(pts), P(y), P(sc), P(sh), 1, P(grid), P(dout), P(mean), P(invstd),
                                      P(G), P(part_a), B, N, C, H, W, *RNG, P(wb), wbn, None))
 timed("cell sort", lambda: lib.call("kd_lidar_cell_sort", P(pts), B, N, H, W, *RNG, P(row), P(start), P(perm), P(ws), wsn, None))
-timed("segmented fwd", lambda: lib.call("kd_lidar_seg_max_fwd", P(y), P(sc), P(sh), 1, P(start), P(perm), P(grid), nc, C, None))
+timed("segmented fwd", lambda: lib.call("kd_lidar_seg_max_fwd", P(y), P(sc), P(sh), 1, P(start), P(perm), None, P(grid), B * N, nc, C, None))
 timed("segmented bwd (+zero rows)", lambda: lib.call("kd_lidar_seg_max_bwd", P(y), P(sc), P(sh), 1, P(grid), P(dout), P(mean), P(invstd),
                                                      P(start), P(perm), P(row), P(G), P(part_s), B * N, nc, C, None))
 spts, srow, start2 = torch.empty_like(pts), torch.empty(B * N, device="cuda", dtype=torch.int32), torch.empty(nc + 1, device="cuda", dtype=torch.int32)
 wpn = lib.kd_lidar_sort_points_ws_bytes(B, N, H, W)
 wp = torch.empty(wpn, device="cuda", dtype=torch.uint8)
 timed("stable point sort", lambda: lib.call("kd_lidar_sort_points", P(pts), B, N, H, W, *RNG, P(spts), P(srow), P(start2), None, P(wp), wpn, None))
-timed("segmented fwd, sorted rows", lambda: lib.call("kd_lidar_seg_max_fwd", P(y), P(sc), P(sh), 1, P(start2), None, P(grid), nc, C, None))
+timed("segmented fwd, sorted rows", lambda: lib.call("kd_lidar_seg_max_fwd", P(y), P(sc), P(sh), 1, P(start2), None, P(srow), P(grid), B * N, nc, C, None))
 timed("segmented bwd, sorted rows", lambda: lib.call("kd_lidar_seg_max_bwd", P(y), P(sc), P(sh), 1, P(grid), P(dout), P(mean), P(invstd),
                                                      P(start2), None, P(srow), P(G), P(part_s), B * N, nc, C, None))
+share, cntw = torch.empty(nc, C, device="cuda"), torch.empty(nc, C, device="cuda")
+part_t = torch.empty(lib.kd_lidar_seg_share_stat_rows(nc, B * N) * 2 * C, device="cuda")
+timed("share-table bwd, sorted rows", lambda: lib.call("kd_lidar_seg_share_bwd", P(y), P(sc), P(sh), 1, P(grid), P(dout), P(mean), P(invstd),
+                                                       P(start2), P(srow), P(share), P(cntw), P(part_t), B * N, nc, C, None))
 nv = int(start[-1])
 print(f"in-range points: {nv} of {B * N}; ideal bytes fwd {nv * C * 4 / 1e9:.2f} GB, bwd {(2 * nv + (B * N - nv)) * C * 4 / 1e9:.2f} GB")
