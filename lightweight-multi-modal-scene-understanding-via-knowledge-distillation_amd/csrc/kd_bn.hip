@@ -132,7 +132,7 @@ __global__ void bn_bwd_finalize_kernel(const float* partial, int rows, int rstep
 struct ApplyArgs {
   const float* x; int64_t ldx; const float* sc; const float* sh; int act;
   const float* res; int64_t ldr; float* out; int64_t ldo;
-  int64_t M; int C; int groups, slots;
+  int64_t M; int C; int groups, slots; int nt;
 };
 __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
   const int tid = threadIdx.x;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
       const float4 r = kd_ld4(a.res + m * a.ldr + c0);
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
-    kd_st4(a.out + m * a.ldo + c0, v);
+    if (a.nt) kd_st4_nt(a.out + m * a.ldo + c0, v); else kd_st4(a.out + m * a.ldo + c0, v);
   }
 }
 
@@ -225,7 +225,7 @@ int kd_bn_act_apply(const float* x, int64_t ldx, const float* sc, const float* s
   KD_REQUIRE(x && out && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, KD_ERR_ARG, "kd_bn_act_apply: bad args (C=%d)", C);
   KD_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && (!res || ldr % 4 == 0), KD_ERR_SHAPE, "kd_bn_act_apply: ld must be a multiple of 4");
   const KdCgLayout l = kd_cg_layout(M, C);
-  ApplyArgs a{x, ldx, sc, sh, act, res, ldr, out, ldo, M, C, l.groups, l.slots};
+  ApplyArgs a{x, ldx, sc, sh, act, res, ldr, out, ldo, M, C, l.groups, l.slots, kd_nt_store((size_t)M * C * sizeof(float))};
   hipLaunchKernelGGL(bn_apply_kernel, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   return kd_check_launch("kd_bn_act_apply");
 }

@@ -62,6 +62,13 @@ __device__ __forceinline__ float kd_act_mask(float z, int act) {
 __device__ __forceinline__ float4 kd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void kd_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 kd_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// streaming variants: tensors written once and read again only by a later kernel (gigabytes later) bypass the
+// cache hierarchy's retention, leaving L2 / MALL to the operands that ARE re-read (weights, per-cell tables)
+__device__ __forceinline__ void kd_st4_nt(float* p, float4 v) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p));
+}
 
 __device__ __forceinline__ float4 kd_affine_act4(float4 x, float4 sc, float4 sh, int act) {
   float4 r;
@@ -103,6 +110,7 @@ __device__ __forceinline__ float kd_wave_sum(float v) {
 }
 
 // out[i] = sum_s slab[s][i], s in fixed order (deterministic); defined in kd_runtime.hip
+int kd_nt_store(size_t bytes);       // 1: a tensor of this size should be stored with the non-temporal hint (KD_NT_STORE=0 disables)
 int kd_slab_reduce_launch(const float* slab, int nsplit, int64_t n, float* out, hipStream_t st);
 int kd_slab_reduce_tall_launch(float* slab, int rows, int64_t n, float* out, hipStream_t st);   // clobbers the slab
 

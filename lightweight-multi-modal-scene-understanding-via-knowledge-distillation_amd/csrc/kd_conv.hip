@@ -97,6 +97,7 @@ struct DwArgs {
   float* y; float* partial;                                       // raw out [B,Ho,Wo,C]; stats slab
   int B, H, W, C, Ho, Wo, stride;
   int groups, slots;
+  int nt;                                                         // large output: non-temporal stores
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -112,6 +113,7 @@ struct DwBwdArgs {
   float* wslab;                        // weight: slab [grid][C*9]
   int B, H, W, C, Ho, Wo, stride;
   int groups, slots;
+  int nt;                              // large gx: non-temporal stores
 };
 
 __device__ __forceinline__ float4 dw_dyeff(const DwBwdArgs& a, int64_t q, int c0, float4 al, float4 be, float4 ga,
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(256) void dw_fwd_sw_kernel(DwArgs a) {
         dw_fma_row(acc, r0, wreg, 0);
         dw_fma_row(acc, r1, wreg, 1);
         dw_fma_row(acc, r2, wreg, 2);
-        kd_st4(a.y + (((int64_t)b * a.Ho + ho) * a.Wo + wo) * a.C + c0, acc);
+        if (a.nt) kd_st4_nt(a.y + (((int64_t)b * a.Ho + ho) * a.Wo + wo) * a.C + c0, acc);
+        else kd_st4(a.y + (((int64_t)b * a.Ho + ho) * a.Wo + wo) * a.C + c0, acc);
         s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
         s2.x = fmaf(acc.x, acc.x, s2.x); s2.y = fmaf(acc.y, acc.y, s2.y);
         s2.z = fmaf(acc.z, acc.z, s2.z); s2.w = fmaf(acc.w, acc.w, s2.w);
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_sw_kernel(DwBwdArgs a) {
           s2.z = fmaf(acc.z, (xr.z - mean.z) * inv.z, s2.z);
           s2.w = fmaf(acc.w, (xr.w - mean.w) * inv.w, s2.w);
         }
-        kd_st4(a.gx + p * a.C + c0, acc);
+        if (a.nt) kd_st4_nt(a.gx + p * a.C + c0, acc); else kd_st4(a.gx + p * a.C + c0, acc);
         r0 = r1; r1 = r2;
       }
     }
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(DwBwdArgs a) {
               s2.w = fmaf(v.w, (xr.w - mean.w) * inv.w, s2.w);
             }
           }
-          if (ok) kd_st4(a.gx + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0, v);
+          if (ok) { if (a.nt) kd_st4_nt(a.gx + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0, v); else kd_st4(a.gx + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0, v); }
         }
         d00 = d10; d01 = d11;
       }
@@ -555,7 +558,8 @@ int kd_dwconv3x3_fwd(const float* x, const float* sc, const float* sh, int act, 
   KD_REQUIRE(kd_aligned16(x) && kd_aligned16(y), KD_ERR_ALIGN, "kd_dwconv3x3_fwd: alignment");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const KdCgLayout l = kd_cg_layout((int64_t)B * Ho * Wo, C);
-  DwArgs a{x, sc, sh, act, w, y, partial, B, H, W, C, Ho, Wo, stride, l.groups, l.slots};
+  DwArgs a{x, sc, sh, act, w, y, partial, B, H, W, C, Ho, Wo, stride, l.groups, l.slots,
+           kd_nt_store((size_t)B * Ho * Wo * C * sizeof(float))};
   if (stride == 1) hipLaunchKernelGGL(dw_fwd_sw_kernel<1>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(dw_fwd_sw_kernel<2>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   return kd_check_launch("kd_dwconv3x3_fwd");
@@ -580,7 +584,7 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
   if (gx) {
     const KdCgLayout l = kd_cg_layout((int64_t)B * H * W, C);
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,
-                nullptr, B, H, W, C, Ho, Wo, stride, l.groups, l.slots};
+                nullptr, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
     if (stride == 1) hipLaunchKernelGGL(dw_bwd_data_sw_kernel, dim3(l.grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dw_bwd_data_s2_kernel, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(data)");
@@ -590,7 +594,7 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
     const KdCgLayout l = kd_cg_layout((int64_t)B * Ho * Wo, C);
     KD_REQUIRE(ws && ws_bytes >= (size_t)l.grid * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, nullptr, nullptr, (float*)ws,
-                B, H, W, C, Ho, Wo, stride, l.groups, l.slots};
+                B, H, W, C, Ho, Wo, stride, l.groups, l.slots, 0};
     if (stride == 1) hipLaunchKernelGGL(dw_bwd_weight_sw_kernel<1>, dim3(l.grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dw_bwd_weight_sw_kernel<2>, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(weight)");

@@ -61,6 +61,7 @@ struct GemmArgs {
   // EPI3 only: m1slab [rowblocks][4][N] receives per-block sums of G0[m][n] * point[m][j] (the part of the layer-0
   // weight gradient that depends on this GEMM's result); with it set, C may be NULL and G0 is never stored.
   float* m1slab;
+  int nt_store;                       // C is large (>= 64 MB): store it with the non-temporal hint
 };
 
 // Tile shape: WM x WN waves of 64x64 each (WM*WN == 4): 128x128 for wide outputs, 256x64 when the
@@ -540,7 +541,9 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 4) ? 3
           s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
         }
       }
-      if (EPI == 3 ? (ok && g.C != nullptr) : ok) kd_st4(g.C + row * g.ldc + col, v);
+      if (EPI == 3 ? (ok && g.C != nullptr) : ok) {
+        if (g.nt_store) kd_st4_nt(g.C + row * g.ldc + col, v); else kd_st4(g.C + row * g.ldc + col, v);
+      }
     }
   }
   if (EPI != 0 && EPI != 5) {
@@ -896,6 +899,7 @@ int launch_wgrad(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
 
 int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {
   const dim3 blk(256);
+  g.nt_store = kd_nt_store((size_t)g.M * g.N * sizeof(float));   // (non-temporal LOADS of A measured neutral: not kept)
   // 256x64 tiles when the last column tile would be <= 64 wide (N = 32, 64, 192, ...)
   const bool tall = ((g.N - 1) % 128) < 64;
   const int64_t M = g.M;
