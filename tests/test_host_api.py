@@ -75,3 +75,24 @@ def test_product_path_refuses_cpu_tensors():
     m = _build("weighted", 128, grid=16)
     with pytest.raises(KDError):
         m(torch.rand(1, 3, 64, 64), torch.rand(1, 32, 4))
+
+
+def test_run_mode_tells_inference_from_eval_with_autograd():
+    """Inside autograd.Function.forward grad mode is always off, so the wrappers decide the execution mode."""
+    from kdrt import units
+    assert units.run_mode(True) == 1
+    assert units.run_mode(False) == 0
+    with torch.no_grad():
+        assert units.run_mode(False) == 2 and units.run_mode(True) == 1
+
+
+def test_point_sort_sharing_is_off_by_default_and_scoped():
+    from kdrt import units
+    assert units._sort_sharing is False and not units._sort_cache
+    units.share_point_bins(True)
+    try:
+        assert units._sort_sharing is True
+        units._sort_cache["points"] = ("key", None, None)
+    finally:
+        units.share_point_bins(False)
+    assert units._sort_sharing is False and not units._sort_cache        # leaving the bracket drops the entries
