@@ -158,7 +158,7 @@ int kd_lidar_cell_sort(const float* pts, int B, int64_t N, int H, int W, float x
 /* the same bins with a deterministic in-cell order (ascending point id), applied to the POINTS: the point MLP then runs
  * on pts_sorted, every grid row owns a contiguous row range (pass perm = NULL to kd_lidar_seg_max_*), the out-of-range
  * points are the tail, and the eval path's compacted list is the first seg_start[B*H*W] rows.  perm may be NULL.
- * KD_ERR_SHAPE (-4) when H*W + 1 > 12288: fall back to kd_lidar_cell_sort. */
+ * KD_ERR_SHAPE (-4) when H*W + 1 > 36865 (144 KB LDS histogram): fall back to kd_lidar_cell_sort. */
 size_t kd_lidar_sort_points_ws_bytes(int B, int64_t N, int H, int W);
 int kd_lidar_sort_points(const float* pts, int B, int64_t N, int H, int W, float x0, float x1, float y0, float y1,
                          float* pts_sorted, int* row_sorted, int* seg_start, int* perm, void* ws, size_t ws_bytes,

@@ -504,7 +504,7 @@ __global__ void seg_fill_kernel(const int* __restrict__ row_of_point, const int*
 // (B) per (frame, key) exclusive prefix over the blocks + totals, global scan of the totals (-> seg_start);
 // (C) scatter: position = seg_start[key] + T[frame][block][key] + block-local rank.
 constexpr int SORT_BLK = 1024;
-constexpr int SORT_MAX_BINS = 12288;          // H*W + 1 ints of LDS
+constexpr int SORT_MAX_BINS = 36865;          // H*W + 1 ints of LDS (144 KB of the CU's 160 KB): grids up to 192 x 192
 
 __global__ __launch_bounds__(SORT_BLK) void stable_count_kernel(const float* __restrict__ pts, int* __restrict__ key_out,
                                                                 int* __restrict__ lrank_out, int* __restrict__ T, int64_t N,
@@ -956,6 +956,11 @@ int kd_lidar_sort_points(const float* pts, int B, int64_t N, int H, int W, float
   int* bsum = inv + B;
   const int nsb = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
   const BevGeom g{x0, x1 - x0, y0, y1 - y0, H, W};
+  if ((size_t)nb * sizeof(int) > 48 * 1024) {      // above the default dynamic-LDS limit: opt in (idempotent, host-side only)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stable_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       SORT_MAX_BINS * (int)sizeof(int));
+    KD_REQUIRE(e == hipSuccess, (int)e, "kd_lidar_sort_points: cannot raise the LDS limit: %s", hipGetErrorString(e));
+  }
   hipLaunchKernelGGL(stable_count_kernel, dim3((unsigned)(B * nblk)), dim3(SORT_BLK), (size_t)nb * sizeof(int), st, pts, key, lrank, T,
                      N, nblk, g);
   const int64_t nbk = (int64_t)B * nb;

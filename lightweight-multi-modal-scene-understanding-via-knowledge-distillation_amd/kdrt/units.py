@@ -823,7 +823,7 @@ def cell_sort(pts, B, N, H, W, rng):
     return out
 
 
-SORT_MAX_BINS = 12288            # kd_lidar_sort_points: H*W + 1 histogram bins in LDS
+SORT_MAX_BINS = 36865            # kd_lidar_sort_points: H*W + 1 histogram bins in LDS (grids up to 192 x 192)
 
 
 def sort_points(pts, B, N, H, W, rng):

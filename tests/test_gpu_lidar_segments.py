@@ -75,7 +75,8 @@ def test_cell_sort_groups_the_in_range_points_by_row(B, N, H, W, pad, nan):
 
 @pytest.mark.parametrize("B,N,H,W,pad,nan", [(1, 257, 4, 4, 0, 0), (3, 5000, 16, 16, 700, 40), (2, 9000, 64, 64, 0, 13),
                                              (2, 40, 32, 32, 0, 0), (5, 3001, 33, 17, 100, 5), (2, 1024, 8, 8, 0, 0),
-                                             (1, 2049, 110, 110, 64, 3)])
+                                             (1, 2049, 110, 110, 64, 3), (2, 3000, 128, 128, 200, 0),
+                                             (1, 1500, 192, 192, 0, 2)])
 def test_sort_points_is_the_stable_sort_by_frame_and_cell(B, N, H, W, pad, nan):
     from kdrt.lib import lib
     pts = _inputs(B, N, 64, 4, pad=pad, nan=nan)[0]
