@@ -220,15 +220,17 @@ def test_gather_sorted_lists_the_in_range_points_in_cell_order():
     assert bool((out_pts[nv:] == -5.0).all()) and bool((out_row[nv:] == -9).all())
 
 
+@pytest.mark.parametrize("sigma", (40.0, 2.0))
 @pytest.mark.parametrize("training", (False, True))
-def test_lidar_encoder_same_bits_with_sorted_and_atomic_scatter(training):
+def test_lidar_encoder_same_bits_with_sorted_and_atomic_scatter(training, sigma):
     """The whole encoder (eval: compaction + fused scatter epilogue; train: forward AND parameter gradients)."""
     from kdrt import units
     from src.models.lidar_encoder import LiDAREncoder
     torch.manual_seed(3)
     enc = LiDAREncoder(encoder_type="spatial", grid_size=(32, 32)).cuda().train(training)
     # (NaN / Inf coordinates only in eval: in train mode they poison the batch statistics, in the reference too)
-    pts = _inputs(2, 6000, 64, 21, pad=500, dup=300, nan=0 if training else 9)[0].view(2, 6000, 4)
+    # sigma = 2 m: a few cells hold more than a thousand points each (the chunked long-row kernels run)
+    pts = _inputs(2, 6000, 64, 21, pad=500, dup=300, nan=0 if training else 9, sigma=sigma)[0].view(2, 6000, 4)
     res = {}
     saved = units._SCATTER_MODE, units._SCATTER_TABLES
     try:
