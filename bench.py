@@ -7,12 +7,21 @@ resident in HBM: concat-fusion teacher forward (eval, no grad) -> weighted-fusio
 all-reduce of the gradients, overlapped with backward) -> fused AdamW.  Every arithmetic kernel is
 a hand-written gfx950 kernel from libkd_hip.so; fp32 end to end (the parity contract is fp32).
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched through
-torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 either launched through
+torch.distributed.run (one rank per GPU, RANK / WORLD_SIZE in the environment) or started bare, in which case
+this process -- before it touches any GPU -- starts its own N ranks as a child `python -m torch.distributed.run`
+and exits with the child's status.  Every rank checks `WORLD_SIZE == --gpus`.  Rank 0 prints ONE JSON line.
+
+`--student-fusion` / `--teacher-fusion` select the fusion variants (the reference's ablation sweep,
+train_with_fusion_ablation.py:87-114: concat / minimal / weighted students); the headline workload is
+concat teacher -> weighted student.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,7 +37,10 @@ MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (same guide); a streaming copy reaches ~5.3-5.6 TB/s
 
 
-def build_models(grid):
+FUSION_CH = {"concat": 256, "minimal": 128, "weighted": 128}     # train_with_fusion_ablation.py:87-91
+
+
+def build_models(grid, teacher_fusion="concat", student_fusion="weighted"):
     from src.models.camera_encoder import TwinLiteEncoder
     from src.models.fusion_module import CompleteSegmentationModel
     from src.models.lidar_encoder import LiDAREncoder
@@ -39,8 +51,8 @@ def build_models(grid):
             num_classes=2, fusion_type=fusion, fusion_out_channels=oc,
             camera_fpn_stages=["stage3", "stage4", "stage5"], camera_fpn_channels=128, output_mode="same")
     torch.manual_seed(0)
-    teacher = mk("concat", 256)
-    student = mk("weighted", 128)
+    teacher = mk(teacher_fusion, FUSION_CH[teacher_fusion])
+    student = mk(student_fusion, FUSION_CH[student_fusion])
     return teacher, student
 
 
@@ -56,15 +68,17 @@ def synth_batch(B, N, HW, grid, seed, device, sigma=40.0):
     return images, pts, labels
 
 
-def cpu_baseline(teacher, student, N, HW, grid, budget_s=20.0):
+def cpu_baseline(teacher, student, N, HW, grid, teacher_fusion, student_fusion, budget_s=30.0):
     """The CPU oracle (oracle/kd_oracle.py, a port of the reference path in stock PyTorch) timed on
-    this box's host cores on a bounded sample of the same workload."""
+    this box's host cores on a bounded sample of the same workload: B=4 frames (the reference's batch),
+    3 warm-up + 10 timed KD steps; the timed count is cut only if the first warm-up
+    step shows the sample would exceed `budget_s`, and the cut is stated in `sample`."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import kd_oracle as O
     # the GPU box exposes 256 logical CPUs but a 1-GPU job owns a 16-core share: use that many threads
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("KD_CPU_THREADS", 16)))
     torch.set_num_threads(cores)
-    B = 2
+    B = 4
     t_st = {k: v.detach().cpu().clone() for k, v in teacher.state_dict().items()}
     s_st = O.clone_state({k: v.detach().cpu().clone() for k, v in student.state_dict().items()}, requires_grad=True)
     images, pts, labels = synth_batch(B, N, HW, grid, 4321, "cpu")
@@ -77,8 +91,8 @@ def cpu_baseline(teacher, student, N, HW, grid, budget_s=20.0):
         for k in keys:
             s_st[k].grad = None
         with torch.no_grad():
-            zt, mt = O.complete_model(images, pts, t_st, fusion_type="concat", grid=(grid, grid), training=False)
-        zs, ms = O.complete_model(images, pts, s_st, fusion_type="weighted", grid=(grid, grid), training=True)
+            zt, mt = O.complete_model(images, pts, t_st, fusion_type=teacher_fusion, grid=(grid, grid), training=False)
+        zs, ms = O.complete_model(images, pts, s_st, fusion_type=student_fusion, grid=(grid, grid), training=True)
         total, _ = O.kd_loss(zs, ms, zt, mt, labels, cw)
         total.backward()
         with torch.no_grad():
@@ -86,15 +100,97 @@ def cpu_baseline(teacher, student, N, HW, grid, budget_s=20.0):
 
     t0 = time.perf_counter()
     one(1)
-    warm = time.perf_counter() - t0
-    iters = max(1, min(5, int(budget_s / max(warm, 1e-3)) - 1))
+    first = time.perf_counter() - t0
+    warm, iters = 3, 10
+    if first * (warm + iters) > budget_s:                     # slower host than planned: keep the run bounded
+        warm = 1
+        iters = max(2, min(10, int(budget_s / max(first, 1e-3)) - warm))
+    for i in range(warm - 1):
+        one(2 + i)
     t0 = time.perf_counter()
     for i in range(iters):
-        one(2 + i)
+        one(1 + warm + i)
     dt = (time.perf_counter() - t0) / iters
+    cut = "" if (warm, iters) == (3, 10) else f" (cut from 3 + 10 to fit {budget_s:.0f} s: first step took {first:.1f} s)"
     return {"value": round(B / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} KD steps of B={B} frames, N={N} points, image {HW}x{HW}, after 1 warm-up step "
-                      f"({dt*1e3:.0f} ms/step, torch CPU threads={torch.get_num_threads()})"}
+            "sample": f"{iters} timed KD steps of B={B} frames after {warm} warm-up steps{cut}, N={N} points, image {HW}x{HW}, "
+                      f"{teacher_fusion} teacher -> {student_fusion} student ({dt*1e3:.0f} ms/step, torch CPU threads={torch.get_num_threads()})"}
+
+
+def kernel_code_state():
+    """Short hash of the kernel sources: stored beside a committed PMC measurement so a stale one is visible."""
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This parent has not touched the
+    GPU (torch.cuda.device_count() does not initialise it) and stays a plain parent: no exec, the ranks are children
+    of a child `python -m torch.distributed.run`; its stdout (rank 0's JSON line) passes straight through."""
+    rehearse = os.environ.get("KD_REHEARSE_ON_ONE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not rehearse:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def selfcheck(args, dev, teacher_fusion, student_fusion):
+    """Correctness gate on the benchmarked size (per-GPU batch B, N points: [B*N, 128] tensors beyond 2^31 elements at
+    the default B=256): a batch made of TWO COPIES of the first B/2 frames must give the same losses and logits as
+    those B/2 frames alone (BatchNorm statistics, mean losses and mean gradients are invariant under duplication), and
+    everything must be finite.  Same seeds as the timed run; fresh models, freed afterwards."""
+    from kdrt import gradsink
+    from kdrt.losses import kd_objective
+    half = args.batch // 2
+    if half < 1:
+        return {"skipped": "per-GPU batch of 1"}
+    images, pts, labels = synth_batch(half, args.points, args.image, args.grid, 1234, dev, args.points_sigma)
+    cw = torch.tensor([0.4, 3.5], device=dev)
+    res = []
+    prev_sink, gradsink.active = gradsink.active, None
+    try:
+        for reps in (1, 2):
+            teacher, student = build_models(args.grid, teacher_fusion, student_fusion)
+            teacher, student = teacher.to(dev).eval(), student.to(dev).train()
+            im, pt, lb = images.repeat(reps, 1, 1, 1), pts.repeat(reps, 1, 1), labels.repeat(reps, 1, 1)
+            with torch.no_grad():
+                zt, mt = teacher(im, pt, return_intermediates=True)
+            zs, ms = student(im, pt, return_intermediates=True)
+            total, parts = kd_objective(zs, ms, zt, mt, lb, cw, 4.0, 1.0, 1.0, -1)
+            total.backward()
+            gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in student.parameters()))
+            vals = {k: float(v) for k, v in parts.items()} | {"total": float(total.detach()), "grad_norm": float(gn)}
+            res.append((vals, zs[:half].detach().clone()))
+            del teacher, student, zt, mt, zs, ms, total, parts, im, pt, lb
+            torch.cuda.empty_cache()
+    finally:
+        gradsink.active = prev_sink
+    (a, za), (b, zb) = res
+    import math
+    finite = all(math.isfinite(x) for x in list(a.values()) + list(b.values()))
+    dl = max(abs(a[k] - b[k]) / max(1.0, abs(a[k])) for k in a if k != "grad_norm")
+    dz = float((za - zb).abs().max()) / max(1.0, float(za.abs().max()))
+    dg = abs(a["grad_norm"] - b["grad_norm"]) / max(a["grad_norm"], 1e-12)
+    ok = finite and dl <= 2e-5 and dz <= 1e-4 and dg <= 2e-2
+    out = {"ok": bool(ok), "what": f"{2*half} frames (two copies of {half}) vs {half} frames, same seeds as the timed run",
+           "losses_at_bench_batch": {k: round(v, 6) for k, v in b.items()}, "max_rel_loss_diff": dl, "max_rel_logit_diff": dz,
+           "rel_grad_norm_diff": dg, "tolerances": {"loss": 2e-5, "logits": 1e-4, "grad_norm": 2e-2}}
+    if not ok:
+        raise SystemExit("bench.py self-check FAILED at the benchmarked size: " + json.dumps(out))
+    return out
 
 
 def main():
@@ -103,22 +199,33 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     # 256 frames/GPU: the larger of the two throughput batches SURVEY.md section 8d names (the reference's B=4 is
-    # launch-bound); 69.7 GiB of the 288 GB HBM.  Measured on one MI355X (final kernels): 4 -> 677 (907 under hipGraph
+    # launch-bound); ~56 GiB of the 288 GB HBM.  Measured on one MI355X (round 1): 4 -> 677 (907 under hipGraph
     # replay), 32 -> 1960, 64 -> 2100, 128 -> 2260, 256 -> 2307 frames/s
     ap.add_argument("--batch", type=int, default=int(os.environ.get("KD_BENCH_BATCH", 256)), help="frames per GPU per step")
     ap.add_argument("--points", type=int, default=80000)
     ap.add_argument("--image", type=int, default=256)
     ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--student-fusion", choices=sorted(FUSION_CH), default="weighted",
+                    help="fusion variant of the student (the ablation sweep of train_with_fusion_ablation.py:87-114)")
+    ap.add_argument("--teacher-fusion", choices=sorted(FUSION_CH), default="concat")
     ap.add_argument("--points-sigma", type=float, default=40.0,
                     help="std (m) of the synthetic x/y coordinates; 40 = the reference's recipe (the headline workload), small "
                          "values pile the points into few BEV cells like the near field of a real sweep (robustness check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-selfcheck", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args)                                    # never returns
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # KD_REHEARSE_ON_ONE_GPU=1: every rank uses cuda:0 and the gloo backend -- only to rehearse the N>1
@@ -128,19 +235,39 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rank_info = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)    # "nccl" is RCCL on ROCm
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        # every rank present and reduced over: an all-reduce of ones must count --gpus ranks; device ids gathered
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        seen = int(ones.item())
+        if seen != args.gpus:
+            raise SystemExit(f"bench.py: all-reduce of ones saw {seen} ranks, expected {args.gpus}")
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
+                "host": socket.gethostname(), "pid": os.getpid()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        if not rehearse and len({(r["host"], r["device"]) for r in gathered}) != world:
+            raise SystemExit(f"bench.py: two ranks share a GPU: {gathered}")
+        rank_info = {"rccl_ranks_seen": seen, "ranks": gathered}
 
     from kdrt import ops
     from kdrt.ddp import BucketedAllReduce, broadcast_module
     from kdrt.kd import KDStep
     from kdrt.optim import FusedAdamW
 
-    teacher, student = build_models(args.grid)
+    check = None
+    if not args.no_selfcheck:
+        check = selfcheck(args, dev, args.teacher_fusion, args.student_fusion)     # every rank checks its own GPU
+        torch.cuda.reset_peak_memory_stats(dev)
+    teacher, student = build_models(args.grid, args.teacher_fusion, args.student_fusion)
     teacher, student = teacher.to(dev).eval(), student.to(dev).train()
     if world > 1:
         broadcast_module(student)
@@ -157,14 +284,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(images, pts, labels)
+    first = None
+    for i in range(args.warmup):
+        parts = step(images, pts, labels)
+        if i == 0:
+            first = parts
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(images, pts, labels)
+        parts = step(images, pts, labels)
+        if first is None:
+            first = parts
     barrier()
     elapsed = time.perf_counter() - t0
+    # outputs of the timed region must be numbers: step-0 and last-step losses, every parameter and moment finite
+    first_losses = {k: float(first[k]) for k in ("total", "ce", "kl", "mse_cam", "mse_lidar")}
+    last_losses = {k: float(parts[k]) for k in ("total", "ce", "kl", "mse_cam", "mse_lidar")}
+    finite = (all(x == x and abs(x) != float("inf") for x in list(first_losses.values()) + list(last_losses.values()))
+              and bool(torch.isfinite(opt.flat.data).all()) and bool(torch.isfinite(opt.flat.grad).all())
+              and bool(torch.isfinite(opt.exp_avg_sq).all()))
+    if world > 1:
+        f = torch.tensor([1.0 if finite else 0.0], device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        finite = bool(f.item() > 0)
+    if not finite:
+        raise SystemExit(f"bench.py: non-finite loss / parameter after the timed steps: {first_losses} -> {last_losses}")
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -176,15 +320,20 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a result)" if rehearse else ""),
         "config": {
-            "workload": "KD step: concat-fusion teacher fwd (eval) -> weighted-fusion student fwd/bwd (train BN), "
-                        "CE + T^2*KL(T=4) + feature-MSE, fused AdamW; random-init weights",
+            "workload": f"KD step: {args.teacher_fusion}-fusion teacher fwd (eval) -> {args.student_fusion}-fusion student fwd/bwd "
+                        "(train BN), CE + T^2*KL(T=4) + feature-MSE, fused AdamW; random-init weights",
+            "teacher_fusion": args.teacher_fusion, "student_fusion": args.student_fusion,
             "image": f"3x{args.image}x{args.image}", "points_per_frame": args.points, "bev_grid": f"{args.grid}x{args.grid}",
             "num_classes": 2, "gemm_arithmetic": ("fp32 operands as 3 bf16 pieces, 6 piece products on the bf16 matrix pipe, fp32 accumulate (fp32-grade)"
                                                    if ops.get_gemm_arithmetic() == "split" else "exact fp32 MFMA products"),
             "per_gpu_batch": args.batch, "global_batch": args.batch * world,
             "parallelism": f"dp{world}" + (" (bucketed RCCL all-reduce overlapped with backward)" if world > 1 else ""),
             "peak_hbm_gib_per_gpu": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)},
+        "checks": {"finite": finite, "losses_step0": {k: round(v, 6) for k, v in first_losses.items()},
+                   "losses_last": {k: round(v, 6) for k, v in last_losses.items()}, "selfcheck": check},
     }
+    if rank_info is not None:
+        out.update(rank_info)
 
     if not args.no_roofline:
         # Live per-kernel timing of the dominant kernel family (the fp32-MFMA pointwise-conv GEMMs):
@@ -247,14 +396,22 @@ def main():
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 wl = pmc["workload"]
-                if (wl["per_gpu_batch"], wl["points_per_frame"], wl["image"], wl["bev_grid"]) == (args.batch, args.points, args.image, args.grid):
+                same = ((wl["per_gpu_batch"], wl["points_per_frame"], wl["image"], wl["bev_grid"]) == (args.batch, args.points, args.image, args.grid)
+                        and wl.get("student_fusion", "weighted") == args.student_fusion
+                        and wl.get("teacher_fusion", "concat") == args.teacher_fusion)
+                if same:
                     out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_unit"] = f"bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/{fn})"
+                    # PMC counters need their own rocprofv3 passes, so this figure is a committed measurement: say which
+                    # kernel sources it was taken on and whether they are the ones running now
+                    out["roofline"]["traffic_code_state"] = pmc.get("code_state")
+                    out["roofline"]["traffic_kernel_hash"] = pmc.get("kernel_hash")
+                    out["roofline"]["traffic_is_current"] = pmc.get("kernel_hash") == kernel_code_state()
                     break
             except (OSError, KeyError, ValueError):
                 continue
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(teacher, student, args.points, args.image, args.grid)
+        out["cpu_baseline"] = cpu_baseline(teacher, student, args.points, args.image, args.grid, args.teacher_fusion, args.student_fusion)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

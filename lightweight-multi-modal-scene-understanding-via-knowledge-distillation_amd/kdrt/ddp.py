@@ -27,6 +27,21 @@ def broadcast_module(module: torch.nn.Module, src: int = 0, group=None):
     """One-time parameter + buffer broadcast from rank `src` (like DDP's init)."""
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+    from . import ops
+    ops.bump_global_epoch()                # `.data` writes do not bump tensor versions: invalidate content-keyed caches
+
+
+def broadcast_buffers(module: torch.nn.Module, src: int = 0, group=None):
+    """BatchNorm running statistics are per replica during training (the reference has no SyncBN); before a validation
+    pass every rank takes rank `src`'s buffers so that all ranks evaluate -- and rank 0 saves -- the same model."""
+    for t in module.buffers():
+        dist.broadcast(t.data, src=src, group=group)
+    from . import ops
+    ops.bump_global_epoch()
+
+
+def distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 class BucketedAllReduce:

@@ -10,7 +10,7 @@ from typing import Optional
 
 import torch
 
-from . import gradsink, units
+from . import gradsink, ops, units
 from .ddp import BucketedAllReduce
 from .losses import kd_objective
 from .optim import FusedAdamW
@@ -99,6 +99,7 @@ class GraphedKDStep:
             self.labels.copy_(labels, non_blocking=True)
         self.step.opt.sync_lr()
         self.graph.replay()
+        ops.bump_global_epoch()            # the replay rewrote parameters and BatchNorm buffers behind torch's back
         self.step.opt.note_steps(1)
         self.replays += 1
         return self.out

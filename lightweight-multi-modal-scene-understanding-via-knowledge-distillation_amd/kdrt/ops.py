@@ -15,6 +15,8 @@ ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 _ws = {}
+_ws_captured = set()      # devices whose current workspace a hipGraph capture has seen
+_ws_keep = []             # retired workspaces that captured graphs still point into
 
 
 def stream() -> int:
@@ -23,12 +25,21 @@ def stream() -> int:
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """One grow-only scratch buffer per device.  All kernels are stream-ordered, and every C entry
-    point consumes its workspace before it returns control to the stream, so sharing is safe."""
+    point consumes its workspace before it returns control to the stream, so sharing is safe.
+    A buffer that was handed out during a hipGraph capture has its address baked into that graph: when a larger
+    request later replaces it, it is retired to `_ws_keep` instead of being freed (a replay would otherwise scribble
+    scratch data over whatever tensor the allocator put there next)."""
     key = (device.type, device.index)
     buf = _ws.get(key)
+    capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and key in _ws_captured:
+            _ws_keep.append(buf)
+            _ws_captured.discard(key)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws[key] = buf
+    if capturing:
+        _ws_captured.add(key)
     return buf
 
 
@@ -100,8 +111,29 @@ def nchw_from_matrix(m: torch.Tensor, geom) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------
+# Epochs of raw-pointer writes (invisible to torch's tensor versions) for caches keyed on parameter / buffer contents:
+# per BatchNorm module (running statistics rewritten by kd_bn_finalize_train), per optimiser (FusedAdamW tags the
+# parameters it owns with itself) and process-wide (hipGraph replays, broadcasts).
+GLOBAL_EPOCH = [0]
+
+
+def bump_global_epoch():
+    GLOBAL_EPOCH[0] += 1
+
+
+def bn_epoch(bn) -> int:
+    return getattr(bn, "_kd_stats_epoch", 0)
+
+
+def owner_epoch(p) -> int:
+    o = getattr(p, "_kd_owner", None)
+    return 0 if o is None else o.epoch
+
+
 def bn_finalize_train(partial, rows, C, count, bn, bnc: BNC, update_running=True, pstride=None):
-    lib.call("kd_bn_finalize_train", P(partial), rows, C, pstride or C, count, P(bn.weight), P(bn.bias), BN_EPS,
+    if update_running:
+        bn._kd_stats_epoch = bn_epoch(bn) + 1
+    lib.call("kd_bn_finalize_train", P(partial), rows, C, pstride or C, count, P(bn.weight), P(bn.bias), float(bn.eps),
              bn.momentum if bn.momentum is not None else BN_MOMENTUM,
              P(bn.running_mean) if update_running else None, P(bn.running_var) if update_running else None,
              P(bn.num_batches_tracked) if update_running else None,

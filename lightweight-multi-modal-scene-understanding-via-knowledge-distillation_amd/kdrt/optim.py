@@ -49,6 +49,9 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
         self._step = 0
+        self.epoch = 0                   # bumped on every device update: caches keyed on parameter contents read it
+        for q in self.flat.params:       # (ops.owner_epoch -- the update goes through raw pointers, not tensor versions)
+            q._kd_owner = self
         self.grad_scale = 1.0            # set to 1/world_size by the DDP wrapper (sum all-reduce)
         # step-to-step state lives on the device so a captured hipGraph of the step replays correctly:
         # dev_state = [lr, step, 1-beta1^step, sqrt(1-beta2^step)]   (kd_adamw_step_dev)
@@ -71,6 +74,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def enqueue_update(self):
         """The device part of a step (two kernel launches, graph-capturable)."""
+        self.epoch += 1
         g = self.param_groups[0]
         lib.call("kd_adamw_step_dev", P(self.flat.data), P(self.flat.grad), P(self.exp_avg), P(self.exp_avg_sq),
                  self.flat.numel, P(self.dev_state), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
@@ -79,6 +83,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def note_steps(self, k: int = 1):
         """Host-side bookkeeping for k device steps (state_dict compatibility with torch.optim.AdamW)."""
         self._step += k
+        self.epoch += 1
         t = torch.tensor(float(self._step))
         for st in self.state.values():
             st["step"] = t
@@ -91,16 +96,21 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        # re-home the loaded moments into the flat buffers
+        # re-home the loaded moments into the flat buffers.  torch.optim.AdamW creates per-parameter state lazily, so a
+        # reference checkpoint may lack it for a parameter that never received a gradient: zeros / step 0 then.
         steps = []
         for p, o in zip(self.flat.params, self.flat.offsets):
             st = self.state[p]
             n = p.numel()
+            if "exp_avg" not in st or "exp_avg_sq" not in st:
+                st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+                st.setdefault("step", torch.tensor(0.0))
             self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
             st["exp_avg"] = self.exp_avg[o:o + n].view(p.shape)
             st["exp_avg_sq"] = self.exp_avg_sq[o:o + n].view(p.shape)
             steps.append(int(float(st["step"])))
         self._step = max(steps) if steps else 0
+        self.epoch += 1
         self.dev_state[1:2].fill_(float(self._step))
         self._dev_lr = None

@@ -45,11 +45,15 @@ def _coeffs(spec: UnitSpec, partial, rows, C, count, training, bnc=None, device=
         bnc = bnc if bnc is not None else BNC(C, device)
         ops.bn_finalize_train(partial, rows, C, count, spec.bn, bnc)
         return bnc
-    # eval mode: the coefficients only depend on the BN's own tensors -- cache them until one changes
-    # (a frozen teacher otherwise recomputes 31 identical coefficient vectors every step)
+    # eval mode: the coefficients only depend on the BN's own tensors -- cache them until one changes (a frozen teacher
+    # otherwise recomputes 31 identical coefficient vectors every step).  The product path rewrites those tensors
+    # through raw device pointers (fused AdamW, kd_bn_finalize_train, graph replays, broadcasts), which torch's
+    # `_version` never sees, so the key carries the writers' own epochs as well: ops.bn_epoch (this module's running
+    # statistics), the epoch of the optimiser that owns gamma / beta, and the process-wide ops.GLOBAL_EPOCH.
     bn = spec.bn
     key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-           bn.weight.data_ptr(), bn.running_mean.data_ptr())
+           bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+           ops.bn_epoch(bn), ops.owner_epoch(bn.weight), ops.owner_epoch(bn.bias), ops.GLOBAL_EPOCH[0])
     if bnc is None:
         hit = getattr(bn, "_kd_eval_cache", None)
         if hit is not None and hit[0] == key:

@@ -183,15 +183,87 @@ class _RawFrames(Dataset):
         return self.ds.load_raw(idx)
 
 
-class DeviceBatchLoader:
-    """DataLoader over raw host frames (any num_workers) + per-batch device preparation in the consumer."""
+class RankShardSampler(torch.utils.data.Sampler):
+    """Frame indices of ONE rank of a data-parallel job.  `equal=True` (training): every rank gets exactly
+    floor(n / world) frames per epoch -- the epoch's permutation (seeded by `seed + epoch`, identical on all ranks) is cut
+    to a multiple of `world` and dealt round-robin -- so that, with drop_last batching, all ranks run the SAME number of
+    steps and none is left waiting in a gradient all-reduce.  `equal=False` (validation: no collectives inside the
+    loop): rank r takes indices r, r + world, ... of the unshuffled set; every frame is seen exactly once job-wide."""
 
-    def __init__(self, ds: PandaSetDataset, batch_size: int, shuffle: bool, num_workers: int, to_cpu: bool = False):
+    def __init__(self, n: int, rank: int, world: int, shuffle: bool, equal: bool, seed: int = 0):
+        if not 0 <= rank < world:
+            raise KDError(f"rank {rank} outside world of {world}")
+        self.n, self.rank, self.world, self.shuffle, self.equal, self.seed, self.epoch = n, rank, world, shuffle, equal, seed, 0
+
+    def set_epoch(self, epoch: int):
+        self.epoch = int(epoch)
+
+    def _order(self):
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            return torch.randperm(self.n, generator=g).tolist()
+        return list(range(self.n))
+
+    def __len__(self):
+        if self.equal:
+            return self.n // self.world
+        return (self.n - self.rank + self.world - 1) // self.world
+
+    def __iter__(self):
+        order = self._order()
+        if self.equal:
+            order = order[: (self.n // self.world) * self.world]
+        return iter(order[self.rank::self.world])
+
+
+def _dist_rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class _EpochLoader:
+    """DataLoader + `set_epoch` forwarded to a RankShardSampler (the trainers call it once per epoch)."""
+
+    def __init__(self, loader: DataLoader, sampler=None):
+        self._loader, self._sampler = loader, sampler
+        self.dataset, self.batch_size = loader.dataset, loader.batch_size
+
+    def set_epoch(self, epoch: int):
+        if self._sampler is not None:
+            self._sampler.set_epoch(epoch)
+
+    def __len__(self):
+        return len(self._loader)
+
+    def __iter__(self):
+        return iter(self._loader)
+
+
+class DeviceBatchLoader:
+    """DataLoader over raw host frames (any num_workers) + per-batch device preparation in the consumer.
+    With `world > 1` the frames are sharded over ranks (RankShardSampler); the training loader then also drops the
+    ragged last batch, so every rank runs the same number of steps."""
+
+    def __init__(self, ds: PandaSetDataset, batch_size: int, shuffle: bool, num_workers: int, to_cpu: bool = False,
+                 rank: int = 0, world: int = 1, train: bool = None):
         self.dataset = ds
         self.batch_size = batch_size
         self.to_cpu = to_cpu
-        self._loader = DataLoader(_RawFrames(ds), batch_size=batch_size, shuffle=shuffle, num_workers=num_workers,
-                                  collate_fn=list)
+        train = shuffle if train is None else train
+        self._sampler = None
+        if world > 1:
+            self._sampler = RankShardSampler(len(ds), rank, world, shuffle=shuffle, equal=train)
+            self._loader = DataLoader(_RawFrames(ds), batch_size=batch_size, sampler=self._sampler, num_workers=num_workers,
+                                      collate_fn=list, drop_last=train)
+        else:
+            self._loader = DataLoader(_RawFrames(ds), batch_size=batch_size, shuffle=shuffle, num_workers=num_workers,
+                                      collate_fn=list)
+
+    def set_epoch(self, epoch: int):
+        if self._sampler is not None:
+            self._sampler.set_epoch(epoch)
 
     def __len__(self):
         return len(self._loader)
@@ -231,14 +303,21 @@ def create_pandaset_dataloaders(root: str, train_scenes: List[str], val_scenes: 
     scripts, which call `.numpy()` on them (test_dataset_distribution.py:22, verify_2class_distribution.py)."""
     if to_cpu is None:
         to_cpu = os.environ.get("KD_LOADER_TO_CPU") == "1"
+    # under torch.distributed (one process per GPU) the FRAMES are sharded over ranks, equal counts per rank for training
+    rank, world = _dist_rank_world()
     if os.path.isdir(root):
         train_ds = PandaSetDataset(root, train_scenes, verbose=verbose)
         val_ds = PandaSetDataset(root, val_scenes, verbose=verbose)
-        return (DeviceBatchLoader(train_ds, batch_size, shuffle=True, num_workers=num_workers, to_cpu=to_cpu),
-                DeviceBatchLoader(val_ds, batch_size, shuffle=False, num_workers=num_workers, to_cpu=to_cpu))
+        return (DeviceBatchLoader(train_ds, batch_size, shuffle=True, num_workers=num_workers, to_cpu=to_cpu, rank=rank, world=world),
+                DeviceBatchLoader(val_ds, batch_size, shuffle=False, num_workers=num_workers, to_cpu=to_cpu, rank=rank, world=world))
     if verbose:
         print(f"[data] '{root}' not found: serving synthetic PandaSet-shaped frames")
     train = SyntheticPandaSet(n_frames=max(8, 8 * len(train_scenes)), seed=1)
     val = SyntheticPandaSet(n_frames=max(4, 4 * len(val_scenes)), seed=2)
+    if world > 1:
+        ts = RankShardSampler(len(train), rank, world, shuffle=True, equal=True)
+        vs = RankShardSampler(len(val), rank, world, shuffle=False, equal=False)
+        return (_EpochLoader(DataLoader(train, batch_size=batch_size, sampler=ts, num_workers=num_workers, pin_memory=True, drop_last=True), ts),
+                _EpochLoader(DataLoader(val, batch_size=batch_size, sampler=vs, num_workers=num_workers, pin_memory=True), vs))
     return (DataLoader(train, batch_size=batch_size, shuffle=True, num_workers=num_workers, pin_memory=True, drop_last=True),
             DataLoader(val, batch_size=batch_size, shuffle=False, num_workers=num_workers, pin_memory=True))

@@ -3,7 +3,8 @@
 Same classes, constructor signatures, attribute names, parameter registration order and
 state_dict keys (reference camera_encoder.py:9-123), so seeds, checkpoints and callers carry
 over.  The layer objects below are parameter containers only: forward never calls them, it hands
-their tensors to the gfx950 kernels through kdrt (exact-fp32 MFMA GEMMs for the 1x1 convs,
+their tensors to the gfx950 kernels through kdrt (MFMA GEMMs for the 1x1 convs -- fp32 storage and
+accumulation, products as bf16x3 split pieces on the bf16 matrix pipe by default, exact-fp32 MFMA with KD_GEMM=fp32;
 NHWC stencils for the depthwise/stem convs, BatchNorm folded into the consumers' loads).
 """
 import torch

@@ -2,10 +2,12 @@
 
 Class names, constructor signatures, buffers and state_dict keys follow the reference
 (lidar_encoder.py:9-221).  The forward runs the point MLP over all B*N points as HIP kernels
-(layer 0 on VALU, layers 1-2 as fp32-MFMA GEMMs), bins points to BEV cells with the reference's
-exact fp32 arithmetic and scatter-maxes with integer atomics (bitwise deterministic).
-`use_vectorized` is accepted for API compatibility: both of the reference's paths give the same
-result, and there is a single device path here.
+(layer 0 recomputed on VALU inside its consumers, layers 1-2 as MFMA GEMMs: fp32 storage / accumulation, split-bf16
+products by default, exact-fp32 MFMA with KD_GEMM=fp32), bins points to BEV cells with the reference's exact fp32
+arithmetic and takes the per-cell maximum over cell-sorted point segments (bitwise deterministic).
+`use_vectorized=False` selects the reference's Python double loop (lidar_encoder.py:101-143): its forward values are
+bit-identical to the vectorized path and its backward raises in the reference (in-place map update), so both flags run
+the one device path here (tests/test_gpu_lidar_iterative_flag.py, tests/golden/lidar_iterative.npz).
 """
 from typing import List, Tuple
 

@@ -20,7 +20,7 @@ import torch.distributed as dist
 import torch.optim as optim
 
 from kdrt import gradsink
-from kdrt.ddp import BucketedAllReduce, broadcast_module
+from kdrt.ddp import BucketedAllReduce, broadcast_buffers, broadcast_module, distributed
 from kdrt.kd import KDStep
 from kdrt.losses import confusion, seg_loss
 from kdrt.optim import FusedAdamW
@@ -50,7 +50,11 @@ class SegmentationMetrics:
 
     def _sync(self):
         if self._dev is not None:
-            self.confusion = self._dev.cpu().numpy().astype(np.int64)
+            g = self._dev
+            if distributed():                       # data parallel: every rank counted its own shard of the frames
+                g = g.clone()                       # (the device matrix keeps this rank's own counts)
+                dist.all_reduce(g)
+            self.confusion = g.cpu().numpy().astype(np.int64)
 
     def compute(self):
         self._sync()
@@ -80,9 +84,19 @@ class Trainer:
         self.criterion = lambda logits, seg: seg_loss(logits, seg, self.class_weights, self.ignore_index)[0]
         self.optimizer = FusedAdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
         self.scheduler = optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=num_epochs, eta_min=1e-5)
-        self.sink = gradsink.install(self.optimizer.flat)        # backward kernels write into the flat grad buffer
+        # Data parallel (torch.distributed initialised, world > 1): every rank starts from rank 0's weights and the
+        # gradients are summed over ranks in buckets as backward produces them (kdrt.ddp), for plain CE training as for KD.
+        self.reducer = None
+        if distributed():
+            broadcast_module(model)
+            names = [n for n, p in model.named_parameters() if p.requires_grad]
+            self.reducer = BucketedAllReduce(self.optimizer.flat, names, n_buckets=3)
+        self.is_main = not distributed() or dist.get_rank() == 0
+        self.sink = gradsink.install(self.optimizer.flat, self.reducer)   # backward kernels write into the flat grad buffer
         self.save_dir = save_dir
-        os.makedirs(save_dir, exist_ok=True)
+        self.epoch = 0
+        if self.is_main:
+            os.makedirs(save_dir, exist_ok=True)
         self.best_miou = 0.0
         self.history_path = os.path.join(save_dir, "training_history.json")
         self.history = {"train_loss": [], "train_miou": [], "val_loss": [], "val_miou": [], "lr": []}
@@ -95,37 +109,52 @@ class Trainer:
         logits = self.model(imgs, pts)
         loss = self.criterion(logits, seg)
         loss.backward()
+        self.optimizer.grad_scale = self.reducer.finish() if self.reducer is not None else 1.0
         self.optimizer.step()
         return loss.detach(), logits.detach()
+
+    def _mean_over_ranks(self, total, n_batches):
+        """(sum of per-batch losses, batch count) -> mean over every rank's batches."""
+        if distributed():
+            t = torch.stack([total.double(), torch.tensor(float(n_batches), device=total.device, dtype=torch.float64)])
+            dist.all_reduce(t)
+            return float(t[0].item() / max(t[1].item(), 1.0))
+        return total.item() / max(n_batches, 1)
 
     def train_epoch(self):
         self.model.train()
         metrics = SegmentationMetrics(num_classes=2)
         total = torch.zeros((), device=self.device)
-        for batch in tqdm(self.train_loader, desc="Train"):
+        if hasattr(self.train_loader, "set_epoch"):       # rank-sharded loaders reshuffle per epoch, identically on all ranks
+            self.train_loader.set_epoch(self.epoch)
+        for batch in tqdm(self.train_loader, desc="Train", disable=not self.is_main):
             imgs = batch["image"].to(self.device, non_blocking=True)
             pts = batch["points"].to(self.device, non_blocking=True)
             seg = batch["segmentation"].to(self.device, non_blocking=True)
             loss, logits = self._step(imgs, pts, seg)
             total += loss                      # stays on the device: no per-step sync
             metrics.update(logits, seg)
-        return total.item() / len(self.train_loader), metrics.compute()
+        return self._mean_over_ranks(total, len(self.train_loader)), metrics.compute()
 
     def validate(self):
         self.model.eval()
+        if distributed():
+            broadcast_buffers(self.model)       # all ranks evaluate rank 0's BatchNorm statistics (the model that is saved)
         metrics = SegmentationMetrics(num_classes=2)
         total = torch.zeros((), device=self.device)
         with torch.no_grad():
-            for batch in tqdm(self.val_loader, desc="Val"):
+            for batch in tqdm(self.val_loader, desc="Val", disable=not self.is_main):
                 imgs = batch["image"].to(self.device, non_blocking=True)
                 pts = batch["points"].to(self.device, non_blocking=True)
                 seg = batch["segmentation"].to(self.device, non_blocking=True)
                 logits = self.model(imgs, pts)
                 total += self.criterion(logits, seg)
                 metrics.update(logits, seg)
-        return total.item() / len(self.val_loader), metrics.compute()
+        return self._mean_over_ranks(total, len(self.val_loader)), metrics.compute()
 
     def save_checkpoint(self, epoch, val_miou, is_best=False):
+        if not self.is_main:
+            return
         ckpt = {"epoch": epoch, "model_state": self.model.state_dict(), "optimizer_state": self.optimizer.state_dict(),
                 "scheduler_state": self.scheduler.state_dict(), "val_miou": val_miou}
         torch.save(ckpt, os.path.join(self.save_dir, "latest.pth"))
@@ -147,13 +176,15 @@ class Trainer:
         for k, v in zip(("train_loss", "train_miou", "val_loss", "val_miou", "lr"),
                         (train_loss, train_miou, val_loss, val_miou, lr)):
             self.history[k].append(v)
-        with open(self.history_path, "w") as f:
-            json.dump(self.history, f, indent=2)
+        if self.is_main:                       # one writer: ranks share the working directory
+            with open(self.history_path, "w") as f:
+                json.dump(self.history, f, indent=2)
 
     def train(self, start_epoch=0):
         print(f"\nStarting training from epoch {start_epoch + 1}/{self.num_epochs}")
         print("=" * 60)
         for epoch in range(start_epoch, self.num_epochs):
+            self.epoch = epoch
             print(f"\nEpoch {epoch+1}/{self.num_epochs}")
             print("-" * 60)
             train_loss, train_metrics = self.train_epoch()
@@ -173,8 +204,7 @@ class Trainer:
             if is_best:
                 self.best_miou = val_miou
                 print(f"  New best mIoU: {val_miou:.4f}")
-            if not dist.is_initialized() or dist.get_rank() == 0:
-                self.save_checkpoint(epoch, val_miou, is_best=is_best)
+            self.save_checkpoint(epoch, val_miou, is_best=is_best)
         print("\n" + "=" * 60)
         print(f"Training completed! Best validation mIoU: {self.best_miou:.4f}")
         print("=" * 60)
@@ -189,12 +219,10 @@ class KDTrainer(Trainer):
     def __init__(self, model, teacher, train_loader, val_loader, device, T=4.0, alpha=1.0, beta=1.0, **kw):
         super().__init__(model, train_loader, val_loader, device, **kw)
         self.teacher = teacher
-        reducer = None
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            broadcast_module(model)
-            names = [n for n, p in model.named_parameters() if p.requires_grad]
-            reducer = BucketedAllReduce(self.optimizer.flat, names, n_buckets=3)
-        self.kd_step = KDStep(model, teacher, self.optimizer, self.class_weights, T, alpha, beta, self.ignore_index, reducer)
+        if distributed():
+            broadcast_module(teacher)           # (a teacher loaded from the same checkpoint on every rank: a no-op in value)
+        self.kd_step = KDStep(model, teacher, self.optimizer, self.class_weights, T, alpha, beta, self.ignore_index, self.reducer)
+        self.sink = self.kd_step.sink
 
     def _step(self, imgs, pts, seg):
         parts = self.kd_step(imgs, pts, seg)

@@ -5,7 +5,10 @@ Environment knobs (defaults reproduce the reference's literals, train_with_fusio
   KD_DATA_ROOT   PandaSet root (reference: a hard-coded Windows path)
   KD_TEACHER     optional checkpoint of a concat-fusion teacher: switches every variant to KD training
   KD_EPOCHS / KD_BATCH_SIZE   20 / 4
-Launch with `python -m torch.distributed.run --nproc-per-node N` for data-parallel training.
+Launch with `python -m torch.distributed.run --nproc-per-node N` for data-parallel training: one process per GPU,
+frames sharded over ranks in equal counts (every rank runs the same number of steps), rank 0's initial weights
+broadcast, gradients all-reduced in buckets during backward (CE and KD training alike), BatchNorm statistics per
+rank while training and rank 0's for validation, metrics summed over ranks, files written by rank 0 only.
 """
 import json
 import os
@@ -56,10 +59,16 @@ def main():
     n_train = int(0.8 * len(all_scenes))
     train_scenes, val_scenes = all_scenes[:n_train], all_scenes[n_train:]
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", 1)) > 1:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        dist.init_process_group("nccl")
-        train_scenes = train_scenes[dist.get_rank()::dist.get_world_size()]      # shard the frames over ranks
-    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        # KD_REHEARSE_ON_ONE_GPU=1: all ranks on cuda:0 over gloo -- exercises the multi-rank code path on a 1-GPU box
+        rehearse = os.environ.get("KD_REHEARSE_ON_ONE_GPU") == "1"
+        torch.cuda.set_device(0 if rehearse else int(os.environ.get("LOCAL_RANK", 0)))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if rehearse else "nccl")   # the loaders shard the frames over ranks themselves
+    device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    main_rank = not dist.is_initialized() or dist.get_rank() == 0
+    if not main_rank:                       # one console: the other ranks train silently
+        import builtins
+        builtins.print = lambda *a, **k: None
     print(f"\n{'='*80}\nFUSION ABLATION STUDY - 2-CLASS DRIVABLE AREA SEGMENTATION\n{'='*80}")
     print(f"Device: {device}\nScenes: {len(train_scenes)} train, {len(val_scenes)} val\n{'='*80}\n")
     results = {}
@@ -72,10 +81,13 @@ def main():
         print(f"{ftype:<12} {data['miou']:>8.4f} {data['total_params']:>15} {data['fusion_params']:>15}")
     best = max(results.items(), key=lambda x: x[1]["miou"])
     print(f"\n{'='*80}\nBEST FUSION: {best[0].upper()}\n  mIoU: {best[1]['miou']:.4f}\n  Total params: {best[1]['total_params']}\n{'='*80}\n")
-    if not dist.is_initialized() or dist.get_rank() == 0:
+    if main_rank:
         with open("fusion_ablation_results.json", "w") as f:
             json.dump(results, f, indent=2)
         print("Results saved to fusion_ablation_results.json")
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -180,6 +180,34 @@ def spatial_lidar_encoder(points, st: State, p: str, grid: Tuple[int, int], trai
     return fmap.view(B, H, W, C).permute(0, 3, 1, 2)               # NCHW view of NHWC memory
 
 
+def spatial_lidar_encoder_iterative(points, st: State, p: str, grid: Tuple[int, int], training: bool,
+                                    x_range=(-50.0, 50.0), y_range=(-50.0, 50.0)):
+    """lidar_encoder.py:101-143 (forward_iterative, `use_vectorized=False`): the same point MLP and binning, then a
+    running `maximum` into a zero-initialised map, one valid point at a time in point order.  Pure-Python loop: small
+    inputs only.  Forward values are bit-identical to `spatial_lidar_encoder`; autograd differs only in how TIED maxima
+    share a cell's gradient (a chain of torch.maximum halves it at every tie: 1/2 to the later point) -- identical
+    points carry identical features, so the PARAMETER gradients still agree (tests/test_oracle_golden.py)."""
+    B, N, _ = points.shape
+    H, W = grid
+    h = points.transpose(1, 2)
+    for i in (0, 3, 6):
+        h = F.conv1d(h, st[f"{p}point_mlp.{i}.weight"], st[f"{p}point_mlp.{i}.bias"])
+        h = _act(_bn(h, st, f"{p}point_mlp.{i+1}", training), "relu")
+    C = h.shape[1]
+    xn, yn, valid = points_to_bev(points, x_range, y_range)
+    ix = (xn * float(W - 1)).to(torch.int64).clamp(0, W - 1)
+    iy = (yn * float(H - 1)).to(torch.int64).clamp(0, H - 1)
+    cells = [[None] * (H * W) for _ in range(B)]                   # running maximum per touched cell
+    for b in range(B):
+        for n in torch.nonzero(valid[b]).flatten().tolist():
+            c = int(iy[b, n]) * W + int(ix[b, n])
+            cur = cells[b][c] if cells[b][c] is not None else torch.zeros(C, dtype=points.dtype)
+            cells[b][c] = torch.maximum(cur, h[b, :, n])
+    zero = torch.zeros(C, dtype=points.dtype)
+    fmap = torch.stack([torch.stack([v if v is not None else zero for v in cells[b]]) for b in range(B)])   # [B, H*W, C]
+    return fmap.view(B, H, W, C).permute(0, 3, 1, 2)
+
+
 # --------------------------------------------------------------------------
 # fusion / heads / full model   (src/models/fusion_module.py)
 # --------------------------------------------------------------------------

@@ -234,6 +234,33 @@ def main():
     with torch.no_grad():
         z4 = m4(images, pts)
     np.savez_compressed(os.path.join(a.out, "head_x4.npz"), logits=z4.numpy())
+    # ---- 7. the iterative LiDAR path (use_vectorized=False, lidar_encoder.py:101-143) --------------
+    # the reference's own Python double loop on the "edge" points (boundaries, 41 exact duplicates, zero-padded tail):
+    # forward values in both modes and, in train mode, the parameter gradients under BOTH flags -- where backward
+    # runs at all: the iterative path updates `feature_map[b, :, y, x]` in place, and autograd raises as soon as a
+    # cell has received two points ("modified by an inplace operation"), i.e. that path is forward-only upstream
+    lid_v = lid_m.SpatialLiDAREncoder(grid_size=(16, 16), use_vectorized=True)
+    lid_i = lid_m.SpatialLiDAREncoder(grid_size=(16, 16), use_vectorized=False)
+    st = O.randomize_state(lid_v.state_dict(), 3)
+    pts = cases["edge"]
+    out = {"points": pts.numpy()}
+    up = torch.randn(2, 128, 16, 16, generator=torch.Generator().manual_seed(5))
+    for mode in ("eval", "train"):
+        ys = {}
+        for tag, enc_ in (("vec", lid_v), ("iter", lid_i)):
+            enc_.load_state_dict(st)
+            enc_.train(mode == "train")
+            ys[tag] = enc_(pts)
+        out[f"iter_{mode}_out"] = ys["iter"].detach().contiguous().numpy()
+        out[f"iter_{mode}_same_bits_as_vectorized"] = np.bool_(torch.equal(ys["iter"], ys["vec"]))
+        if mode == "train":
+            try:
+                (ys["iter"] * up).sum().backward()
+                out["iter_backward"] = np.array("ok")
+            except RuntimeError as e:          # in-place map update: autograd refuses -- a forward-only path upstream
+                out["iter_backward"] = np.array("RuntimeError: " + str(e).split(":")[0])
+    np.savez_compressed(os.path.join(a.out, "lidar_iterative.npz"), **out)
+
     print("golden fixtures written to", os.path.abspath(a.out))
     for f in sorted(os.listdir(a.out)):
         print(f"  {f}: {os.path.getsize(os.path.join(a.out, f))/1024:.1f} KiB")

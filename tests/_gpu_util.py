@@ -1,4 +1,4 @@
-"""Helpers shared by the GPU parity tests and tests/gpu_diag.py."""
+"""Helpers shared by the GPU parity tests and tools/gpu_diag.py."""
 import torch
 
 import kd_oracle as O

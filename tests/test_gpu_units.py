@@ -181,7 +181,7 @@ def test_fusion_and_head_small(fusion):
     stf, sth = _rand_state(fus, 41), _rand_state(head, 42)
     fus, head = fus.cuda().train(), head.cuda().train()
     # data seed 7: with seed 6 the split arithmetic lands one pre-activation on the other side of a ReLU kink
-    # (tests/gpu_diag_flip.py: seeds 7..13 agree to <= 1.6e-6 in both arithmetics, seed 6 flips under "split" only)
+    # (tools/gpu_diag_flip.py: seeds 7..13 agree to <= 1.6e-6 in both arithmetics, seed 6 flips under "split" only)
     g = torch.Generator().manual_seed(7)
     cam, lid = torch.randn(2, 128, 10, 10, generator=g), torch.randn(2, 128, 10, 10, generator=g).clamp_min(0)
     cg, lg = cam.clone().cuda().requires_grad_(True), lid.clone().cuda().requires_grad_(True)

@@ -117,6 +117,23 @@ def test_lidar_edges(case):
                                            rtol=1e-3, err_msg=k)
 
 
+@pytest.mark.parametrize("mode", ("eval", "train"))
+def test_lidar_iterative_path(mode):
+    """the reference's `use_vectorized=False` loop (lidar_encoder.py:101-143), run by the
+    reference itself on the edge-case points: same bits as its vectorized path, and forward-only (its backward raises
+    autograd's in-place error as soon as one cell has received two points)."""
+    gd = golden("lidar_iterative.npz")
+    assert bool(gd[f"iter_{mode}_same_bits_as_vectorized"])
+    assert str(gd["iter_backward"]).startswith("RuntimeError: one of the variables needed for gradient computation")
+    pts = torch.from_numpy(gd["points"])
+    st = _lidar_state(3)
+    with torch.no_grad():
+        yi = O.spatial_lidar_encoder_iterative(pts, O.clone_state(st), "", (16, 16), training=(mode == "train"))
+        yv = O.spatial_lidar_encoder(pts, O.clone_state(st), "", (16, 16), training=(mode == "train"))
+    assert torch.equal(yi, yv)                                     # the two restatements agree bit for bit as well
+    np.testing.assert_allclose(yi.numpy(), gd[f"iter_{mode}_out"], atol=TOL, rtol=0)
+
+
 def test_scatter_tie_rule():
     # SURVEY 8 a-5 probe: src [1,1,.5]->cell0, [0,0]->cell1 gives grads [.5,.5,0, 1/3,1/3]
     src = torch.tensor([[1.0], [1.0], [0.5], [0.0], [0.0]], requires_grad=True)

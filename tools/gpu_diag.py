@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-for p in (HERE, os.path.join(ROOT, "oracle"),
+for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"),
           os.path.join(ROOT, "lightweight-multi-modal-scene-understanding-via-knowledge-distillation_amd")):
     sys.path.insert(0, p)
 import torch  # noqa: E402

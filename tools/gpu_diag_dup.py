@@ -1,6 +1,6 @@
 """Dev diagnostic: gradient agreement between a batch and two copies of it, at several sizes / arithmetics."""
 import os, sys
-sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
+sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")]
 import conftest  # noqa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
 """Dev diagnostic: where does the duplicated-batch gradient mismatch come from?  Module by module, loss = mean(out^2)."""
 import os, sys
-sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
+sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")]
 import conftest  # noqa
 import torch
 from src.models.camera_encoder import TwinLiteEncoder, InvertedResidual

@@ -1,6 +1,6 @@
 """Dev diagnostic: InvertedResidual stride 2 -- GPU gradients vs the CPU oracle at batch 2 and at the duplicated batch 4."""
 import os, sys
-sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
+sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")]
 import conftest  # noqa
 import torch
 import kd_oracle as O

@@ -1,6 +1,6 @@
 """Dev diagnostic: duplicated-batch gradient differences of the full KD step, absolute scale."""
 import os, sys
-sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
+sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")]
 import conftest  # noqa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
 """Dev diagnostic: test_fusion_and_head_small[weighted] input-gradient error per data seed and GEMM arithmetic."""
 import sys, os
-sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
+sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")]
 import conftest  # noqa: F401  (sys.path)
 import torch
 import kd_oracle as O

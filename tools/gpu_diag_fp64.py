@@ -2,7 +2,7 @@
 next to the fp32 CPU oracle.  Shows how much of the model-level gradient mismatch is conditioning (BatchNorm-backward
 cancellation), i.e. present in ANY fp32 evaluation."""
 import os, sys
-sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
+sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")]
 import conftest  # noqa
 import torch
 import kd_oracle as O

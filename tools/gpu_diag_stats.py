@@ -1,6 +1,6 @@
 """Dev diagnostic: BN-backward sums (dgrad EPI2 partial slab -> kd_bn_bwd_finalize) for M = 8192 vs 16384 rows."""
 import os, sys
-sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
+sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")]
 import conftest  # noqa
 import torch
 from kdrt import ops
