@@ -78,11 +78,19 @@ class BucketedAllReduce:
     def reset(self):
         for b, (a, e) in enumerate(self.spans):
             self.pending[b] = e - a
+        self.seen = [False] * len(self.flat.params)
         self.handles = []
         self.launch_order = []
 
     def _make_hook(self, i):
+        # A parameter counts ONCE per step, whichever path reports it first.  With the direct gradient sink the backward
+        # Function reports the write itself (GradSink.done -> notify) and returns None to autograd -- and autograd still
+        # runs the parameter's AccumulateGrad node afterwards and fires this hook a second time (observed on torch 2.10:
+        # every bucket was launched when HALF of its gradients had landed, and the ranks diverged).
         def hook(_p):
+            if self.seen[i]:
+                return
+            self.seen[i] = True
             b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0:

@@ -52,8 +52,21 @@ def main():
 
     def logged(b):
         orders[-1].append(b)
+        if os.environ.get("KD_DDP_SYNC") == "1":   # debugging aid: blocking reduce after a device sync
+            torch.cuda.synchronize()
+            dist.all_reduce(red.views[b])
+            torch.cuda.synchronize()
+            return
         launch(b)
     red._launch = logged
+    notes = {}
+    notify = red.notify
+
+    def counted(p):
+        i = red.index_of[id(p)]
+        notes.setdefault(i, []).append(sum(len(o) for o in orders))      # buckets launched so far when this gradient landed
+        notify(p)
+    red.notify = counted
     step = KDStep(student, teacher, opt, cw, reducer=red)
     orders.append([])
     parts = step(*batch(rank))
@@ -95,10 +108,24 @@ def main():
         "rank": rank, "orders": orders, "total": float(parts["total"]),
         "grad_err": (summed - want_sum).abs().max().item() / scale,
         "param_err": (after1 - o3.flat.data).abs().max().item(),
+        "err_vs_own_only": (summed - grads[rank]).abs().max().item() / scale,
+        "err_vs_other_only": (summed - grads[1 - rank]).abs().max().item() / scale,
+        "bucket_err": [((summed - want_sum)[opt.flat.offsets[a]:opt.flat.offsets[e]]).abs().max().item() / scale for a, e in red.spans],
         "bn_own": max((bn1[k] - bns[rank][k]).abs().max().item() for k in bn1),
         "bn_other": max((bn1[k] - bns[1 - rank][k]).abs().max().item() for k in bn1),
         "grad_scale": opt.grad_scale,
     }
+    if os.environ.get("KD_DDP_DEBUG") == "1":
+        other = summed.clone()
+        dist.broadcast(other, src=0)
+        res["summed_same_on_both_ranks"] = bool(torch.equal(other, summed))
+        rows = []
+        for i, nm in enumerate(names):
+            a, e = opt.flat.offsets[i], opt.flat.offsets[i] + opt.flat.params[i].numel()
+            rows.append((nm, red.bucket_of[i], notes.get(i), (summed[a:e] - want_sum[a:e]).abs().max().item(),
+                         (summed[a:e] - grads[rank][a:e]).abs().max().item(), (summed[a:e] - grads[1 - rank][a:e]).abs().max().item(),
+                         want_sum[a:e].abs().max().item()))
+        res["rows"] = rows
     # every rank holds the same parameters after the steps
     mine = opt.flat.data.clone()
     ref = mine.clone()

@@ -213,3 +213,60 @@ def test_gradsink_drives_bucketed_allreduce_world2_unequal_shards():
     for rank, orders, scale, twice in res:
         assert orders == [[2, 1, 0], [2, 1, 0]], orders              # head -> fusion -> camera, every step
         assert scale == 0.5 and twice
+
+
+def test_bucket_fires_only_after_all_its_gradients_with_sink_and_autograd_hooks():
+    """The product pattern on CPU: an autograd.Function whose backward writes the parameter gradients into the sink and
+    returns None for them.  torch (2.10) still runs the parameters' AccumulateGrad nodes and fires the post-accumulate
+    hooks the reducer registered; each parameter must nevertheless count once, so a bucket is launched only when ALL
+    its gradients are in the flat buffer (round 1 launched every bucket at the half-way point on the GPU path)."""
+    from kdrt import gradsink
+    from kdrt.ddp import BucketedAllReduce
+    from kdrt.optim import FlatParams
+    names = ["enc.w1", "enc.b1", "enc.w2", "enc.b2", "head.w", "head.b"]
+    ps = [torch.nn.Parameter(torch.full((4,), float(i + 1))) for i in range(6)]
+    flat = FlatParams(ps)
+    red = BucketedAllReduce(flat, names, n_buckets=2)
+    assert red.spans == [(0, 4), (4, 6)]
+    events = []
+    launch = red._launch
+
+    def logged(b):
+        a, e = red.spans[b]
+        events.append(("launch", b, [bool(flat.grad[flat.offsets[i]:flat.offsets[i] + 4].abs().sum() > 0) for i in range(a, e)]))
+        launch(b)
+    red._launch = logged
+    sink = gradsink.install(flat, red)
+
+    class Layer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.w, ctx.b = w, b
+            return x + 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            for p in (ctx.w, ctx.b):
+                buf, direct = gradsink.out_for(p)
+                assert direct
+                buf.copy_(torch.full((4,), 3.0))
+                events.append(("write", names[red.index_of[id(p)]]))
+                assert gradsink.finish(p, buf, direct) is None
+            return g, None, None
+
+    try:
+        for step in range(2):
+            events.clear()
+            sink.begin_step()
+            flat.zero_grad()
+            x = torch.ones(4, requires_grad=True)
+            y = Layer.apply(Layer.apply(Layer.apply(x, ps[0], ps[1]), ps[2], ps[3]), ps[4], ps[5])
+            y.sum().backward()
+            assert red.finish() == 1.0
+            launches = [e for e in events if e[0] == "launch"]
+            assert [e[1] for e in launches] == [1, 0], events
+            assert all(all(e[2]) for e in launches), events            # every gradient of the bucket was already written
+            assert events.index(launches[1]) > events.index(("write", "enc.b1"))
+            assert torch.equal(flat.grad, torch.full_like(flat.grad, 3.0))
+    finally:
+        gradsink.uninstall()

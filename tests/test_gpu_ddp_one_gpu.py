@@ -43,7 +43,7 @@ def test_two_ranks_equal_two_replicas_with_averaged_gradients(tmp_path):
     res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
     for r in res:
         assert r["orders"] == [[2, 1, 0], [2, 1, 0]], r["orders"]        # bucket launch order, both steps
-        assert r["grad_err"] <= 1e-6, r                                    # summed gradients == replica 0 + replica 1
+        assert r["grad_err"] <= 1e-6, json.dumps(r)                                    # summed gradients == replica 0 + replica 1
         assert r["param_err"] <= 1e-7, r                                   # one AdamW step on the averaged gradient
         assert r["bn_own"] == 0.0 and r["bn_other"] > 0.0, r               # BatchNorm buffers stay per rank
         assert r["grad_scale"] == 0.5 and r["ranks_agree"]
