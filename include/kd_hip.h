@@ -53,6 +53,12 @@ const char* kd_last_error_string(void);
  * (error <= 2^-23 |x||y| per product, i.e. fp32-grade).  Process-wide; returns the previous setting. */
 int kd_set_gemm_split(int on);
 int64_t kd_pwconv_stat_rows(int64_t M);
+int64_t kd_pwconv_stat_rows_for(int64_t M, int K, int N, int pro, int epi);
+/* Rows of the statistics slab the launch for (K, N, pro, epi) will write in the current arithmetic (one per wave for the
+ * weight-resident streaming kernels of kd_gemm_stream.hip, one per 128 matrix rows for the tiled kernels): size the slab and
+ * drive kd_bn_finalize_train / kd_bn_bwd_finalize with it.  kd_set_gemm_stream: 0 = tiled kernels only, 1 = streaming
+ * kernels where they are faster (default; env KD_GEMM_STREAM=0|1|all), 2 = every covered shape; returns the previous mode. */
+int kd_set_gemm_stream(int mode);
 int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, int pro, int pro_act,
                    const float* p0, const float* p1, const float* p2, const float* p3, const float* p4,
                    const float* W, const float* bias, float* C, int64_t ldc, const float* addend,

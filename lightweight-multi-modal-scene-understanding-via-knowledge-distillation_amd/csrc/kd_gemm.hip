@@ -10,7 +10,7 @@
 //
 // MFMA: v_mfma_f32_32x32x2_f32 -- fp32 in, fp32 accumulate, bit-exact fmaf chain, 157 TFLOP/s
 // dense peak on MI355X.  Tiles: 128x128 (or 256x64) per 256-thread workgroup, 4 waves x (2x2) 32x32 MFMA tiles.
-#include "kd_common.h"
+#include "kd_gemm_args.h"
 
 #include <atomic>
 
@@ -38,32 +38,6 @@ __device__ unsigned long long kd_dbg_counters[8];
 
 constexpr int BM = 128, BK = 32, LDSLD = 36;   // BM: slab-row granularity; 36-float LDS rows: ds_read_b128 conflict-free
 
-struct GemmArgs {
-  const float* A; int64_t lda;        // PRO0/1: raw activations; PRO2: D (gradient)
-  const float* A2; int64_t lda2;      // PRO2: X raw (the conv output whose BN is differentiated)
-  const float* p0; const float* p1; const float* p2;   // PRO1: sc, sh ; PRO2: al, be, ga  (per K)
-  const float* p3; const float* p4;   // PRO2 with mask: sc, sh of the masked activation (per K)
-  int pro; int pro_act;
-  const float* W;                     // [N][K] row-major
-  const float* bias;                  // [N] or null
-  float* C; int64_t ldc;
-  const float* addend; int64_t ldadd; // optional: C += addend (before the EPI2 mask)
-  const float* X; int64_t ldx;        // EPI2: raw tensor whose activation is differentiated [M,N]
-  const float* esc; const float* esh; const float* emean; const float* einv; int epi_act;
-  float* partial;                     // EPI1/2: [rowblocks][2][N]
-  int M, K, N;
-  const int* m_dev;                   // optional: device-side row count (<= M); rows beyond it are skipped
-  const float* l0w; const float* l0b; // PRO3 / EPI3: LiDAR layer-0 weight [C0][4] and bias [C0] (A or X = points [M,4])
-  // PRO4: the scatter-max gradient rebuilt on load.  A = Y raw [M,K]; trows[m] = grid row of point m (< 0: none);
-  // tmx / tshare = [cells][K] tables (cell maximum, dout / holders): G = (v > 0 && v == mx) ? share : 0 with
-  // v = act(Y*p3 + p4), then the PRO2 formula al*G + be*Y + ga.
-  const float* tmx; const float* tshare; const int* trows;
-  // EPI3 only: m1slab [rowblocks][4][N] receives per-block sums of G0[m][n] * point[m][j] (the part of the layer-0
-  // weight gradient that depends on this GEMM's result); with it set, C may be NULL and G0 is never stored.
-  float* m1slab;
-  int nt_store;                       // C is large (>= 64 MB): store it with the non-temporal hint
-};
-
 // Tile shape: WM x WN waves of 64x64 each (WM*WN == 4): 128x128 for wide outputs, 256x64 when the
 // last (or only) column tile would be at most 64 wide (N = 32, 64, 192, ...) so no MFMA work is
 // wasted on padding columns.
@@ -76,7 +50,6 @@ struct GemmArgs {
 // against 8 x 64 cycles of v_mfma_f32_32x32x2_f32): 6 x 32 = 192 cycles per 32x32x16 block instead of 512, so the
 // near-ridge shapes of this network (AI 14..64 FLOP/B) become HBM-bound instead of matrix-pipe-bound.
 // (LDS image of the split operands: see SPROW below.)
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 // Split LDS image: [plane][row][32 bf16], rows of exactly 64 bytes, no padding, with the four 16-byte chunks of a
 // row XOR-swizzled by (row >> 2) & 3.  ds_read_b128 is served in lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (and
 // the same +32): the four rows of a group that share row % 4 then land in four different chunks, so the 16 lanes tile
@@ -84,27 +57,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 // kinds are conflict-free and the image is 20 % smaller than with padded rows (49 KB for 128x128: 3 workgroups / CU).
 constexpr int SPROW = 32;                               // bf16 per row
 __device__ __forceinline__ int kd_sw_chunk(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 8; }   // element offset
-
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-
-// two fp32 -> packed (hi | mid | lo) bf16 pairs, each piece rounded to nearest even by v_cvt_pk_bf16_f32:
-// |mid| <= 2^-9 |x|, |lo| <= 2^-17 |x|, x - (hi + mid + lo) <= 2^-26 |x|, residual signs unbiased.
-__device__ __forceinline__ void kd_split_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-  f32x2 v = {x0, x1};
-  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-  v[0] -= __uint_as_float(hi << 16);                 // exact (Sterbenz-like: hi shares the leading bits of x)
-  v[1] -= __uint_as_float(hi & 0xffff0000u);
-  mid = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-  v[0] -= __uint_as_float(mid << 16);
-  v[1] -= __uint_as_float(mid & 0xffff0000u);
-  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-
-__device__ __forceinline__ void kd_split3(float4 v, uint2& hi, uint2& mid, uint2& lo) {
-  kd_split_pair(v.x, v.y, hi.x, mid.x, lo.x);
-  kd_split_pair(v.z, v.w, hi.y, mid.y, lo.y);
-}
 
 template <int PRO, int EPI, int WM, int WN, bool SPLIT>
 // Occupancy: 3 workgroups / CU wherever 168 registers and 3 x 49 KB of LDS allow it (fp32: all but the 256x64 PRO2
@@ -905,6 +857,11 @@ int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {
   const int64_t M = g.M;
   const int64_t ntile = tall ? ((M + 255) / 256) * ((g.N + 63) / 64) : ((M + 127) / 128) * ((g.N + 127) / 128);
   const bool split = g_gemm_split.load(std::memory_order_relaxed) != 0;
+  if (split) {        // skinny shapes whose weights fit in LDS: the weight-resident streaming kernels (kd_gemm_stream.hip)
+    const int rc = kd_gemm_stream_launch(g, pro, epi, st);
+    if (rc < 0) return KD_ERR_ARG;
+    if (rc > 0) return KD_OK;
+  }
   const dim3 grid((unsigned)ntile);
 #define KD_GEMM_CASE(P_, E_)                                                                       \
   if (pro == P_ && epi == E_) {                                                                    \
@@ -959,6 +916,16 @@ int kd_dbg_read(unsigned long long* out, int reset) {
 
 // Rows of the BN-statistics slab a GEMM over M rows writes ([rows][2][N] floats).
 int64_t kd_pwconv_stat_rows(int64_t M) { return (M + BM - 1) / BM; }
+// ... for the launch the dispatcher will actually make for (K, N, pro, epi) in the current arithmetic: the streaming
+// kernels write one row per wave (<= 1024), the tiled kernels one per 128 matrix rows.  Callers size the slab AND tell
+// kd_bn_finalize_train / kd_bn_bwd_finalize how many rows to sum with this number.
+int64_t kd_pwconv_stat_rows_for(int64_t M, int K, int N, int pro, int epi) {
+  if (g_gemm_split.load(std::memory_order_relaxed)) {
+    const int r = kd_gemm_stream_stat_rows(M, K, N, pro, epi);
+    if (r > 0) return r;
+  }
+  return (M + BM - 1) / BM;
+}
 
 // Forward / dgrad GEMM.  See include/kd_hip.h for the argument contract.
 int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, int pro, int pro_act, const float* p0,

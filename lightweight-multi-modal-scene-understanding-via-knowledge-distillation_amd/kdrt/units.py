@@ -85,7 +85,8 @@ def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] 
             y = torch.empty(M, N, device=dev, dtype=torch.float32)
         partial, rows = None, 0
         if training:
-            rows = lib.kd_pwconv_stat_rows(M)
+            pro = 3 if inp.virt is not None else (1 if inp.bnc is not None else 0)
+            rows = lib.kd_pwconv_stat_rows_for(M, K, N, pro, 1)         # streaming kernels: one row per wave; tiled: per 128 rows
             partial = torch.empty(rows * 2 * N, device=dev, dtype=torch.float32)
         if inp.virt is not None:
             ops.l1_fwd(inp, w, y, bias=b, epi=1 if training else 0, partial=partial, m_dev=m_dev)

@@ -197,7 +197,11 @@ def test_kd_gradients_against_fp64_oracle():
     """Gradient accuracy without the flip-tolerant comparison: the oracle evaluated in float64 is the ground truth, and the
     GPU gradients must be as close to it as the fp32 CPU oracle is (measured: both ~2.5e-6 median, < 1e-5 max)."""
     from kdrt.losses import kd_objective
-    images, pts, labels = O.make_inputs(B, HW, N, G, 4, pad_tail=40)
+    # Input seed 8: no pre-activation of this batch sits within fp32 rounding of a ReLU / ReLU6 / max kink, so every
+    # evaluation -- CPU fp32, GPU in both GEMM arithmetics, tiled or streaming kernels -- stays on the float64 side
+    # (tools/diag_fp64_seeds.py scans seeds x configurations; seed 4, used until round 2, flips in the fp32 CPU oracle
+    # itself under some thread counts, and seed 7 under the split arithmetic: 3e-3 instead of 3e-6, by construction).
+    images, pts, labels = O.make_inputs(B, HW, N, G, 8, pad_tail=40)
     cw = torch.tensor([0.4, 3.5])
 
     def oracle(dtype):
