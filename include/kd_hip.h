@@ -57,7 +57,8 @@ int64_t kd_pwconv_stat_rows_for(int64_t M, int K, int N, int pro, int epi);
 /* Rows of the statistics slab the launch for (K, N, pro, epi) will write in the current arithmetic (one per wave for the
  * weight-resident streaming kernels of kd_gemm_stream.hip, one per 128 matrix rows for the tiled kernels): size the slab and
  * drive kd_bn_finalize_train / kd_bn_bwd_finalize with it.  kd_set_gemm_stream: 0 = tiled kernels only, 1 = streaming
- * kernels where they are faster (default; env KD_GEMM_STREAM=0|1|all), 2 = every covered shape; returns the previous mode. */
+ * kernels only for the shapes that win in isolation, 2 = every covered shape (default; env KD_GEMM_STREAM=0|1|all);
+ * returns the previous mode. */
 int kd_set_gemm_stream(int mode);
 int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, int pro, int pro_act,
                    const float* p0, const float* p1, const float* p2, const float* p3, const float* p4,

@@ -224,9 +224,12 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
   // ---- epilogue: register q of a block is row (q & 3) + 8 (q >> 2) + 4 h, column r.  Neighbouring lanes swap one value of
   // each register pair so that a lane stores 8 contiguous bytes: 128-byte row segments, 32 stores per slab instead of 64
   // (vmcnt counts stores too: with at most 16 loads + 32 stores younger than a slab's first load the waits stay exact). -----
-  const int c_lane = (4 * h + (odd ? 1 : 0)) * (int)g.ldc + (r & ~1);    // floats, per lane, fixed
-  const int ad_lane = (4 * h + (odd ? 1 : 0)) * (int)g.ldadd + (r & ~1);
-  const bool has_bias = g.bias != nullptr;
+  // Epilogue: register q of a block is row (q & 3) + 8 (q >> 2) + 4 h, column r -- one dword store per register writes two
+  // 128-byte row segments (rows R and R + 4), full-rate for plain stores (MI355X_MICROARCH.md).  Addresses are a wave-uniform
+  // base plus a per-lane offset that never changes.  (A variant that swapped values between neighbouring lanes to store
+  // 8 bytes per lane halved the store count but cost two DPP moves and two selects per pair: slower, not kept.)
+  const int c_lane = 4 * h * (int)g.ldc + r;                             // floats, per lane, fixed
+  const int ad_lane = 4 * h * (int)g.ldadd + r;
   auto store_slab = [&](int64_t s, f32x16 (&acc)[NB], auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;              // every row of the slab is < M: no predicates at all
     const int64_t m0 = s * 32;
@@ -235,47 +238,30 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
     for (int j = 0; j < NB; ++j) {
       float* cbase = g.C + m0 * g.ldc + n0 + 32 * j;               // wave-uniform
       const float* abase = addend ? addend + m0 * g.ldadd + n0 + 32 * j : nullptr;
-      float2 ad[8];
-      if (EPI == 5 && addend) {                                   // residual rows, in the layout of the stores below
+      float ad[16];
+      if (EPI == 5 && addend) {                                   // residual values, in the layout of the stores below
 #pragma unroll
-        for (int q = 0; q < 16; q += 2) {
+        for (int q = 0; q < 16; ++q) {
           const int rbase = (q & 3) + 8 * (q >> 2);
-          const bool rok = FULL || (m0 + rbase + 4 * h + (odd ? 1 : 0) < M);
-          ad[q >> 1] = rok ? *reinterpret_cast<const float2*>(abase + (int64_t)rbase * g.ldadd + ad_lane) : make_float2(0.f, 0.f);
+          const bool rok = FULL || (m0 + rbase + 4 * h < M);
+          ad[q] = rok ? abase[(int64_t)rbase * g.ldadd + ad_lane] : 0.f;
         }
       }
 #pragma unroll
-      for (int q = 0; q < 16; q += 2) {
+      for (int q = 0; q < 16; ++q) {
         const int rbase = (q & 3) + 8 * (q >> 2);                  // row of register q within the slab, before + 4 h
-        float v0 = acc[j][q], v1 = acc[j][q + 1];
-        if (has_bias) { v0 += bias[j]; v1 += bias[j]; }            // (wave-uniform branch: most convolutions here have no bias)
-        if (EPI == 1) {
-          if (FULL || m0 + rbase + 4 * h < M) { s1[j] += v0; s2[j] = fmaf(v0, v0, s2[j]); }
-          if (FULL || m0 + rbase + 4 * h + 1 < M) { s1[j] += v1; s2[j] = fmaf(v1, v1, s2[j]); }
-        }
+        const bool rok = FULL || (m0 + rbase + 4 * h < M);
+        float v = acc[j][q] + bias[j];
+        if (EPI == 1 && rok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
         if (EPI == 5) {
-          v0 = kd_act(kd_affine(v0, esc[j], esh[j]), g.epi_act);
-          v1 = kd_act(kd_affine(v1, esc[j], esh[j]), g.epi_act);
+          v = kd_act(kd_affine(v, esc[j], esh[j]), g.epi_act);
+          if (addend) v += ad[q];
         }
-        // even lane: (row R, cols c, c + 1) = (own v0, neighbour's v0); odd lane: (row R + 1, cols c - 1, c) = (neighbour's v1, own v1)
-        // (both moves run with every lane active -- a DPP read from a lane that EXEC has switched off returns 0 -- so their
-        // results are made opaque: left alone, hipcc sinks each move into the divergent arm of the select that uses it)
-        float x0 = kd_xor1(v0), x1 = kd_xor1(v1);
-        asm volatile("" : "+v"(x0), "+v"(x1));
-        float lo = odd ? x1 : v0, hi = odd ? v1 : x0;
-        if (EPI == 5 && addend) { lo += ad[q >> 1].x; hi += ad[q >> 1].y; }
-        typedef __attribute__((ext_vector_type(2))) float f2v;
-        const f2v out = {lo, hi};
-        f2v* dst = reinterpret_cast<f2v*>(cbase + (int64_t)rbase * g.ldc + c_lane);
-#ifdef KD_S_NOST            // ablation build: results kept alive, no stores
-        asm volatile("" :: "v"(lo), "v"(hi), "v"(dst));
-        if (false) {
-#else
+        float* dst = cbase + (int64_t)rbase * g.ldc + c_lane;
         if (FULL) {
-#endif
-          if (g.nt_store) __builtin_nontemporal_store(out, dst); else *dst = out;
-        } else if (m0 + rbase + 4 * h + (odd ? 1 : 0) < M) {
-          *dst = out;
+          if (g.nt_store) __builtin_nontemporal_store(v, dst); else *dst = v;
+        } else if (rok) {
+          *dst = v;
         }
       }
     }
@@ -330,11 +316,11 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
 
 std::atomic<int> g_stream_on{-1};
 
-int stream_mode() {          // 0 off, 1 where it wins (default), 2 every covered shape
+int stream_mode() {          // 0 off, 1 only the shapes that win in isolation, 2 every covered shape (default)
   int v = g_stream_on.load(std::memory_order_relaxed);
   if (v < 0) {
     const char* e = getenv("KD_GEMM_STREAM");
-    v = (e && e[0] == '0') ? 0 : ((e && e[0] == 'a') ? 2 : 1);
+    v = (e && e[0] == '0') ? 0 : ((e && e[0] == '1') ? 1 : 2);
     g_stream_on.store(v, std::memory_order_relaxed);
   }
   return v;
@@ -353,11 +339,11 @@ bool stream_cfg(int K, int N, int pro, int epi, StreamCfg& c) {
   if (!(kb == 1 || kb == 2 || kb == 4) || !(nb == 1 || nb == 2 || nb == 4)) return false;
   if (pro == 3 && kb != 2) return false;
   c = {kb, nb, 1};
-  if (stream_all()) return true;                  // KD_GEMM_STREAM=all: every covered shape (A/B measurements)
-  // Where the streaming form wins on an MI355X (tools/bench_stream, M = 32 frames; profiles/r02_stream_vs_tiled.txt):
-  // outputs of 32 / 64 channels (1.1-1.5x: the tiled kernel pads them to 64-column MFMA tiles and stages them through
-  // LDS twice), the 128 -> 128 layers (1.05-1.18x) and the LiDAR layer-1 forward with its statistics (1.2x).  The
-  // 64 -> 128 layers with a BatchNorm prologue run 0.85-0.95x (their k-loop is shorter than the epilogue) and stay tiled.
+  // Measured on an MI355X: per shape at M = 32 frames the streaming form runs 1.0-1.45x the tiled kernel (profiles/
+  // r02_stream_vs_tiled.txt; only the 64 -> 128 layers with a BatchNorm prologue at multi-million M lose, 0.8-0.9x), and in
+  // the whole KD step at 256 frames "every covered shape" beats "only where the micro-benchmark wins" (95.5 vs 96.6 ms
+  // per step; 97.1 ms with the tiled kernels alone) -- so every covered shape is the default; mode 1 keeps the narrow rule.
+  if (stream_all()) return true;
   return nb <= 2 || (kb == 4 && nb == 4) || (pro == 3 && epi == 1);
 }
 
