@@ -5,6 +5,8 @@
 //               BN stats in the epilogue); backward = transposed stencil + per-channel weight sums.
 #include "kd_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -344,6 +346,110 @@ __global__ __launch_bounds__(256) void dw_bwd_data_sw_kernel(DwBwdArgs a) {
   if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
 }
 
+// stride-1 data AND weight gradient in one pass (the separate kernels read the folded dy and the raw input twice: seven
+// tensor passes over HBM; fused: four).  Same column-segment walk as dw_bwd_data_sw_kernel; the weight gradient rides on
+// its dy window (see the loop).  The raw centre of each input row doubles as the operand of the activation mask and of
+// the BatchNorm-backward sums.  A segment's last dy row and first / last input rows reach into the neighbouring segments:
+// every (dy row, input row) pair is still counted exactly once, by the segment that owns the INPUT row.
+__global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
+  __shared__ float red[2 * 256 * 4];
+  __shared__ __attribute__((aligned(16))) float wl[9 * 1024];   // flipped taps, [tap][channel]: wl[t][c] = w[c][8 - t] (C <= 1024)
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  const bool active = slot < a.slots;
+  const int c0 = gidx * 4;
+  float4 s1 = kd_zero4(), s2 = kd_zero4();
+  float4 wacc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wacc[t] = kd_zero4();
+  for (int i = tid; i < a.C * 9; i += 256) wl[(i % 9) * a.C + i / 9] = a.w[(i / 9) * 9 + (8 - i % 9)];
+  __syncthreads();
+  // (the nine taps live in LDS, not in 36 registers: with the dy window, the input window, the weight-gradient
+  // accumulators and the one-row-ahead prefetch the kernel would otherwise spill)
+  auto fma_row = [&](float4& acc, const DwRow& r, int kh) {
+    const float4 w0 = kd_ld4(wl + (kh * 3 + 0) * a.C + c0), w1 = kd_ld4(wl + (kh * 3 + 1) * a.C + c0), w2 = kd_ld4(wl + (kh * 3 + 2) * a.C + c0);
+    acc.x = fmaf(r.l.x, w0.x, fmaf(r.c.x, w1.x, fmaf(r.r.x, w2.x, acc.x)));
+    acc.y = fmaf(r.l.y, w0.y, fmaf(r.c.y, w1.y, fmaf(r.r.y, w2.y, acc.y)));
+    acc.z = fmaf(r.l.z, w0.z, fmaf(r.c.z, w1.z, fmaf(r.r.z, w2.z, acc.z)));
+    acc.w = fmaf(r.l.w, w0.w, fmaf(r.c.w, w1.w, fmaf(r.r.w, w2.w, acc.w)));
+  };
+  if (active) {
+    float4 al = kd_zero4(), be = kd_zero4(), ga = kd_zero4(), dsc = kd_zero4(), dsh = kd_zero4();
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4(), mean = kd_zero4(), inv = kd_zero4();
+    if (a.al) { al = kd_ld4(a.al + c0); be = kd_ld4(a.be + c0); ga = kd_ld4(a.ga + c0); }
+    if (a.dsc) { dsc = kd_ld4(a.dsc + c0); dsh = kd_ld4(a.dsh + c0); }
+    const bool deferred = a.sc != nullptr;
+    if (deferred) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
+    if (a.mean) { mean = kd_ld4(a.mean + c0); inv = kd_ld4(a.invstd + c0); }
+    const int nseg = (a.H + DW_SEG - 1) / DW_SEG;
+    const int64_t items = (int64_t)a.B * nseg * a.W;
+    for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+      const int wi = (int)(it % a.W), sg = (int)((it / a.W) % nseg), b = (int)(it / ((int64_t)a.W * nseg));
+      const int h0 = sg * DW_SEG, h1 = h0 + DW_SEG < a.H ? h0 + DW_SEG : a.H;
+      DwRow r0 = dw_load_dy_row(a, al, be, ga, dsc, dsh, b, h0 - 1, wi, c0);
+      DwRow r1 = dw_load_dy_row(a, al, be, ga, dsc, dsh, b, h0, wi, c0), r2;
+      // One row AHEAD (in-order vmcnt: a wait on a load that FOLLOWS a store also waits for the store): the raw dy row
+      // hi + 1 and the raw input row hi are requested before the store of row hi - 1 is issued.
+      DwRaw nl = dw_dy_raw_s1(a, b, h0 + 1, wi - 1, c0), nc = dw_dy_raw_s1(a, b, h0 + 1, wi, c0), nr = dw_dy_raw_s1(a, b, h0 + 1, wi + 1, c0);
+      DwRow xn = dw_load_row_raw(a.x, b, h0, wi, a.H, a.W, a.C, c0);
+      for (int hi = h0; hi < h1; ++hi) {
+        {
+          const bool hok = hi + 1 < a.Ho;
+          r2.l = dw_dy_finish(a, nl, hok && wi - 1 >= 0, al, be, ga, dsc, dsh);
+          r2.c = dw_dy_finish(a, nc, hok, al, be, ga, dsc, dsh);
+          r2.r = dw_dy_finish(a, nr, hok && wi + 1 < a.Wo, al, be, ga, dsc, dsh);
+        }
+        const float4 xr = xn.c;                                           // raw centre: mask + BatchNorm-backward operand of row hi
+        const DwRow xa = dw_finish_row(xn, deferred, sc, sh, a.act, hi, wi, a.H, a.W);
+        nl = dw_dy_raw_s1(a, b, hi + 2, wi - 1, c0); nc = dw_dy_raw_s1(a, b, hi + 2, wi, c0); nr = dw_dy_raw_s1(a, b, hi + 2, wi + 1, c0);
+        xn = dw_load_row_raw(a.x, b, hi + 1 < a.H ? hi + 1 : hi, wi, a.H, a.W, a.C, c0);
+        // ---- weight gradient.  dw[kh][kw] = sum_ho dy(ho) x(ho - 1 + kh, wo - 1 + kw): the input row hi pairs with the dy
+        // centres of rows hi + 1 (kh = 0), hi (kh = 1), hi - 1 (kh = 2), all three in the dy window (zero outside the image),
+        // so no input window is kept: every input row is activated once and used once. ---------------------------------
+#define KD_DW_WG(KH, D)                                                                                            \
+  wacc[KH * 3 + 0].x = fmaf(D.x, xa.l.x, wacc[KH * 3 + 0].x); wacc[KH * 3 + 0].y = fmaf(D.y, xa.l.y, wacc[KH * 3 + 0].y); \
+  wacc[KH * 3 + 0].z = fmaf(D.z, xa.l.z, wacc[KH * 3 + 0].z); wacc[KH * 3 + 0].w = fmaf(D.w, xa.l.w, wacc[KH * 3 + 0].w); \
+  wacc[KH * 3 + 1].x = fmaf(D.x, xa.c.x, wacc[KH * 3 + 1].x); wacc[KH * 3 + 1].y = fmaf(D.y, xa.c.y, wacc[KH * 3 + 1].y); \
+  wacc[KH * 3 + 1].z = fmaf(D.z, xa.c.z, wacc[KH * 3 + 1].z); wacc[KH * 3 + 1].w = fmaf(D.w, xa.c.w, wacc[KH * 3 + 1].w); \
+  wacc[KH * 3 + 2].x = fmaf(D.x, xa.r.x, wacc[KH * 3 + 2].x); wacc[KH * 3 + 2].y = fmaf(D.y, xa.r.y, wacc[KH * 3 + 2].y); \
+  wacc[KH * 3 + 2].z = fmaf(D.z, xa.r.z, wacc[KH * 3 + 2].z); wacc[KH * 3 + 2].w = fmaf(D.w, xa.r.w, wacc[KH * 3 + 2].w);
+        KD_DW_WG(0, r2.c) KD_DW_WG(1, r1.c) KD_DW_WG(2, r0.c)
+#undef KD_DW_WG
+        // ---- data gradient ---------------------------------------------------------------------------------------------------
+        float4 acc = kd_zero4();
+        fma_row(acc, r0, 0);
+        fma_row(acc, r1, 1);
+        fma_row(acc, r2, 2);
+        const int64_t p = ((int64_t)b * a.H + hi) * a.W + wi;
+        if (deferred) {
+          acc.x *= kd_act_mask(kd_affine(xr.x, sc.x, sh.x), a.act);
+          acc.y *= kd_act_mask(kd_affine(xr.y, sc.y, sh.y), a.act);
+          acc.z *= kd_act_mask(kd_affine(xr.z, sc.z, sh.z), a.act);
+          acc.w *= kd_act_mask(kd_affine(xr.w, sc.w, sh.w), a.act);
+          s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+          s2.x = fmaf(acc.x, (xr.x - mean.x) * inv.x, s2.x);
+          s2.y = fmaf(acc.y, (xr.y - mean.y) * inv.y, s2.y);
+          s2.z = fmaf(acc.z, (xr.z - mean.z) * inv.z, s2.z);
+          s2.w = fmaf(acc.w, (xr.w - mean.w) * inv.w, s2.w);
+        }
+        if (a.nt) kd_st4_nt(a.gx + p * a.C + c0, acc); else kd_st4(a.gx + p * a.C + c0, acc);
+        r0 = r1; r1 = r2;
+      }
+    }
+  }
+  if (a.partial) { dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots); }
+  for (int t = 0; t < 9; ++t) {        // per-block weight-gradient partials, summed in fixed order by kd_slab_reduce
+    __syncthreads();
+    kd_st4(red + tid * 4, active ? wacc[t] : kd_zero4());
+    __syncthreads();
+    for (int c = tid; c < a.C; c += 256) {
+      float s = 0.f;
+      for (int sl = 0; sl < a.slots; ++sl) s += red[(sl * a.groups + c / 4) * 4 + (c & 3)];
+      a.wslab[(int64_t)blockIdx.x * a.C * 9 + c * 9 + t] = s;
+    }
+  }
+}
+
 // stride-2 data gradient.  Work item = a column of 2x2 input QUADS (b, 8 quad rows, quad column q): the quad with
 // top-left input pixel (2a, 2q) receives from exactly the four outputs (a, q), (a, q+1), (a+1, q), (a+1, q+1):
 //   gx(2a  , 2q  ) = d00 w11                      gx(2a  , 2q+1) = d01 w10 + d00 w12
@@ -520,6 +626,11 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_sw_kernel(DwBwdArgs a) {
 
 }  // namespace
 
+static bool kd_dw_fused_enabled() {     // KD_DW_FUSED=0: the separate data / weight kernels (A/B, tests)
+  static const int on = [] { const char* e = getenv("KD_DW_FUSED"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on != 0;
+}
+
 extern "C" {
 
 int64_t kd_stem_stat_rows(int64_t npix) {
@@ -581,6 +692,16 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
   KD_REQUIRE(!sc || (sh && (!partial || (mean && invstd))), KD_ERR_ARG, "kd_dwconv3x3_bwd: sc needs sh (+mean/invstd for stats)");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
+  if (gx && dw && stride == 1 && kd_dw_fused_enabled()) {      // one pass: data gradient + statistics + weight-gradient partials
+    const KdCgLayout l = kd_cg_layout((int64_t)B * H * W, C);
+    KD_REQUIRE(ws && ws_bytes >= (size_t)l.grid * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
+    DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,
+                (float*)ws, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
+    hipLaunchKernelGGL(dw_bwd_fused_s1_kernel, dim3(l.grid), dim3(256), 0, st, a);
+    int rc = kd_check_launch("kd_dwconv3x3_bwd(fused)");
+    if (rc) return rc;
+    return kd_slab_reduce_launch((const float*)ws, l.grid, (int64_t)C * 9, dw, st);
+  }
   if (gx) {
     const KdCgLayout l = kd_cg_layout((int64_t)B * H * W, C);
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,

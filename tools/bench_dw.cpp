@@ -27,15 +27,16 @@ int main() {
   auto timeit = [&](auto fn) { fn(); CK(hipDeviceSynchronize()); CK(hipEventRecord(e0)); for (int i = 0; i < 5; ++i) fn();
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / 5; };
   float *sc = vec, *sh = vec + 1024, *al = vec + 2048, *be = vec + 3072, *ga = vec + 4096, *mean = vec + 5120, *inv = vec + 6144, *w = vec + 8192;
-  printf("%-26s | %-22s | %-22s | %-22s\n", "shape (B=32)", "fwd (+stats)", "bwd data (+stats)", "bwd weight");
+  printf("%-26s | %-22s | %-22s | %-22s | %-30s\n", "shape (B=32)", "fwd (+stats)", "bwd data (+stats)", "bwd weight", "bwd data + weight in one call");
   for (auto& s : shapes) {
     const int Ho = (s.H - 1) / s.s + 1, Wo = (s.W - 1) / s.s + 1;
     const double in = 4.0 * B * s.H * s.W * s.C, out = 4.0 * B * Ho * Wo * s.C;
     float tf = timeit([&] { RC(kd_dwconv3x3_fwd(x, sc, sh, 2, w, y, partial, B, s.H, s.W, s.C, s.s, nullptr)); });
     float td = timeit([&] { RC(kd_dwconv3x3_bwd(d, y, al, be, ga, nullptr, nullptr, 0, x, sc, sh, 2, mean, inv, w, gx, partial, nullptr, B, s.H, s.W, s.C, s.s, ws, wsb, nullptr)); });
     float tw = timeit([&] { RC(kd_dwconv3x3_bwd(d, y, al, be, ga, nullptr, nullptr, 0, x, sc, sh, 2, mean, inv, w, nullptr, nullptr, dw, B, s.H, s.W, s.C, s.s, ws, wsb, nullptr)); });
-    printf("%-26s | %7.1fus %5.2f TB/s    | %7.1fus %5.2f TB/s    | %7.1fus %5.2f TB/s\n", s.name, tf * 1e3, (in + out) / tf / 1e9,
-           td * 1e3, (2 * out + 2 * in) / td / 1e9, tw * 1e3, (2 * out + in) / tw / 1e9);
+    float tb = timeit([&] { RC(kd_dwconv3x3_bwd(d, y, al, be, ga, nullptr, nullptr, 0, x, sc, sh, 2, mean, inv, w, gx, partial, dw, B, s.H, s.W, s.C, s.s, ws, wsb, nullptr)); });
+    printf("%-26s | %7.1fus %5.2f TB/s    | %7.1fus %5.2f TB/s    | %7.1fus %5.2f TB/s    | %7.1fus %5.2f TB/s (vs %.1fus separately)\n", s.name, tf * 1e3, (in + out) / tf / 1e9,
+           td * 1e3, (2 * out + 2 * in) / td / 1e9, tw * 1e3, (2 * out + in) / tw / 1e9, tb * 1e3, (2 * out + 2 * in) / tb / 1e9, (td + tw) * 1e3);
   }
   return 0;
 }
