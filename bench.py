@@ -117,6 +117,35 @@ def cpu_baseline(teacher, student, N, HW, grid, teacher_fusion, student_fusion, 
                       f"{teacher_fusion} teacher -> {student_fusion} student ({dt*1e3:.0f} ms/step, torch CPU threads={torch.get_num_threads()})"}
 
 
+def bf16_forward_bench(args, dev, images, pts, steps):
+    """BASELINE.json configs[1]: camera + LiDAR concat-fusion FORWARD with bf16 activations (kdrt/bf16.py, csrc/kd_bf16.hip),
+    timed beside the fp32 eval forward of the same model on the same batch; reports both rates, the logit error and the
+    argmax agreement at this size.  A second mode: never the headline, never a substitute for the fp32 parity contract."""
+    from kdrt.bf16 import forward_bf16
+    _, model = build_models(args.grid, "concat", "concat")
+    model = model.to(dev).eval()
+
+    def rate(fn):
+        for _ in range(2):
+            z = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            z = fn()
+        torch.cuda.synchronize()
+        return args.batch * steps / (time.perf_counter() - t0), z
+
+    with torch.no_grad():
+        r32, z32 = rate(lambda: model(images, pts))
+    r16, z16 = rate(lambda: forward_bf16(model, images, pts))
+    rng = float(z32.max() - z32.min())
+    return {"metric": "concat-fusion forward frames/sec, bf16 activations in HBM (fp32 accumulate)", "dtype": "bf16",
+            "value": round(r16, 1), "unit": "frames/s", "fp32_forward_frames_per_s": round(r32, 1), "speedup_vs_fp32_forward": round(r16 / r32, 2),
+            "steps": steps, "per_gpu_batch": args.batch, "points_per_frame": args.points,
+            "max_abs_logit_error_vs_fp32": round(float((z16 - z32).abs().max()), 4), "logit_range": round(rng, 2),
+            "argmax_agreement_vs_fp32": round(float((z16.argmax(1) == z32.argmax(1)).float().mean()), 5)}
+
+
 def kernel_code_state():
     """Short hash of the kernel sources: stored beside a committed PMC measurement so a stale one is visible."""
     h = hashlib.sha256()
@@ -214,6 +243,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-selfcheck", action="store_true")
+    ap.add_argument("--no-bf16-forward", action="store_true", help="skip the bf16-storage forward line (configs[1])")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -410,6 +440,10 @@ def main():
                     break
             except (OSError, KeyError, ValueError):
                 continue
+    if rank == 0 and world == 1 and not args.no_bf16_forward:
+        del step
+        torch.cuda.empty_cache()
+        out["bf16_forward"] = bf16_forward_bench(args, dev, images, pts, max(3, min(args.steps, 10)))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(teacher, student, args.points, args.image, args.grid, args.teacher_fusion, args.student_fusion)
     if rank == 0:

@@ -280,6 +280,28 @@ int kd_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float
 int kd_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, float beta1,
                       float beta2, float eps, float weight_decay, float ginv, void* stream);
 
+/* ---- bf16-storage INFERENCE path (csrc/kd_bf16.hip; BASELINE.json configs[1]) -----------------------------------------
+ * A second mode beside the fp32 contract: eval forward only.  Activations are bf16 NHWC matrices [M][C], already
+ * normalised + activated; every entry point is one whole unit conv -> fma(raw, sc, sh) -> act (+ residual) -> bf16, with
+ * fp32 accumulation; weights / coefficient vectors are fp32.  Replaces, in eval mode: the stem (camera_encoder.py:63-67),
+ * depthwise 3x3 (:30-35, fusion_module.py:25-27,78), every 1x1 conv / Conv1d(k=1) (camera_encoder.py:24,39,
+ * fusion_module.py:12,29, lidar_encoder.py:26-34 incl. the scatter-max of :85-96), the FPN resize + sum (:58-63) and the
+ * classifier (:170).  kd_bf16_pwconv: a_kind 0 = A bf16, 1 = A fp32 (rounded on load), 3 = A are LiDAR points [M][4] and
+ * layer 0 (l0w [K][4], l0b, sc0, sh0, act0) is recomputed; epi 0 = C bf16 (+ res bf16), 4 = scatter-max of the
+ * non-negative result into the zero-filled fp32 grid [cells][ldgrid] by cell[m] (< 0: skipped). */
+int kd_bf16_stem(const float* x_nchw, const float* w, const float* sc, const float* sh, int act, void* y, int B, int Cin, int H,
+                 int W, int Cout, void* stream);
+int kd_bf16_dwconv3x3(const void* x, const float* w, const float* sc, const float* sh, int act, void* y, int B, int H, int W,
+                      int C, int stride, void* stream);
+int kd_bf16_pwconv(const void* A, int64_t lda, int a_kind, const float* W, const float* bias, const float* esc, const float* esh,
+                   int act, void* C, int64_t ldc, const void* res, int64_t ldres, int epi, int64_t M, int K, int N,
+                   const int* m_dev, const float* l0w, const float* l0b, const float* sc0, const float* sh0, int act0,
+                   const int* cell, float* grid, int64_t ldgrid, void* stream);
+int kd_bf16_bilinear_sum(const void* in0, int H0, int W0, const void* in1, int H1, int W1, const void* in2, int H2, int W2,
+                         void* out, int B, int Ho, int Wo, int C, void* stream);
+int kd_bf16_cls_conv(const void* x, const float* w, const float* b, float* logits_nchw, int64_t M, int HW, int Cin, int NC,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

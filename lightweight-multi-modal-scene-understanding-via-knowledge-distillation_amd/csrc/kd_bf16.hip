@@ -1,0 +1,496 @@
+// kd_bf16.hip -- bf16-STORAGE inference path (BASELINE.json configs[1]: "camera+LiDAR concat-fusion forward ... bf16").
+//
+// A second, separately gated mode next to the fp32 contract: eval-mode forward only, activations live in HBM as bf16
+// (NHWC, already normalised + activated: in eval mode BatchNorm coefficients are known before a convolution runs, so every
+// unit is ONE kernel: conv -> fma(raw, scale, shift) -> activation (+ residual) -> bf16), accumulation in fp32, weights and
+// BatchNorm coefficients stay fp32 in HBM (the GEMM rounds its weight tile to bf16 once, when it parks it in LDS).  The
+// 1x1 convolutions are plain bf16 MFMA GEMMs (v_mfma_f32_32x32x16_bf16, ONE product per element instead of the six of the
+// fp32-grade split arithmetic) in the weight-resident streaming form of kd_gemm_stream.hip: a lane reads its A fragment
+// -- 8 consecutive bf16 of its row, 16 bytes -- straight from HBM as the MFMA operand; no conversion, no LDS for A.
+// Reference layers: camera_encoder.py:19-67, fusion_module.py:8-91,162-173, lidar_encoder.py:25-35,57-99.
+//
+// Accuracy is that of bf16 activations (8-bit mantissa): see tests/test_gpu_bf16.py for the measured logit error and the
+// argmax agreement with the fp32 path -- this mode is NOT part of the fp32 parity contract.
+#include "kd_common.h"
+
+#include <cstdlib>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef unsigned short bf16_t;                       // storage type
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {          // round to nearest even, NaN stays NaN
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ void unpack8(u32x4 u, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = bf_lo(u[i]); f[2 * i + 1] = bf_hi(u[i]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  return u32x4{pk_bf16(f[0], f[1]), pk_bf16(f[2], f[3]), pk_bf16(f[4], f[5]), pk_bf16(f[6], f[7])};
+}
+__device__ __forceinline__ u32x4 ld16(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(bf16_t* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// stem: 3x3 / s2 dense conv on the NCHW fp32 image, Cout == 32 (camera_encoder.py:63-67) -> act(bn(.)) as bf16 NHWC.
+__global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sc,
+                                                        const float* __restrict__ sh, int act, bf16_t* __restrict__ y, int B, int Cin,
+                                                        int H, int W, int Ho, int Wo) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int KK = Cin * 9;
+  float* ws = sm;                      // [KK][32] tap-major
+  for (int i = threadIdx.x; i < KK * 32; i += 256) ws[(i % KK) * 32 + i / KK] = w[i];
+  __syncthreads();
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    float acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+    const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), b = (int)(p / ((int64_t)Wo * Ho));
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* xp = x + ((int64_t)b * Cin + ci) * H * W;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hi = 2 * ho - 1 + kh;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int wi = 2 * wo - 1 + kw;
+          float v = 0.f;
+          if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = xp[(int64_t)hi * W + wi];
+          const float* wt = ws + (ci * 9 + kh * 3 + kw) * 32;
+#pragma unroll
+          for (int c = 0; c < 32; ++c) acc[c] = fmaf(v, wt[c], acc[c]);
+        }
+      }
+    }
+    bf16_t* yp = y + p * 32;
+#pragma unroll
+    for (int c = 0; c < 32; c += 8) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = kd_act(kd_affine(acc[c + j], sc[c + j], sh[c + j]), act);
+      st16(yp + c, pack8(o));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// depthwise 3x3 (stride 1 / 2, pad 1) on an ACTIVATED bf16 input; output act(conv * scale + shift) as bf16.
+// A thread owns 8 channels (16 bytes) of a column segment and slides a 3-row window down it; taps in LDS ([tap][C]).
+struct DwBfArgs {
+  const bf16_t* x; const float* w; const float* sc; const float* sh; int act; bf16_t* y;
+  int B, H, W, C, Ho, Wo, stride, groups, slots;
+};
+constexpr int DWB_SEG = 16;
+
+struct Row8 { float l[8], c[8], r[8]; };
+
+__device__ __forceinline__ void dwb_load_row(const DwBfArgs& a, int b, int hi, int wi, int c0, Row8& o) {
+  const bool hok = hi >= 0 && hi < a.H;
+  const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi);
+  const bf16_t* rowp = a.x + ((int64_t)b * a.H + hic) * a.W * a.C + c0;
+  const bool lok = hok && wi - 1 >= 0, rok = hok && wi + 1 < a.W;
+  const int wl = wi - 1 < 0 ? 0 : wi - 1, wr = wi + 1 >= a.W ? a.W - 1 : wi + 1;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  const u32x4 l = ld16(rowp + (int64_t)wl * a.C), c = ld16(rowp + (int64_t)wi * a.C), r = ld16(rowp + (int64_t)wr * a.C);
+  unpack8(lok ? l : z, o.l);
+  unpack8(hok ? c : z, o.c);
+  unpack8(rok ? r : z, o.r);
+}
+
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw_bf16_kernel(DwBfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];      // [9][C]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < a.C * 9; i += 256) wl[(i % 9) * a.C + i / 9] = a.w[i];
+  __syncthreads();
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  if (slot >= a.slots) return;
+  const int c0 = gidx * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = a.sc[c0 + j]; sh[j] = a.sh[c0 + j]; }
+  const int nseg = (a.Ho + DWB_SEG - 1) / DWB_SEG;
+  const int64_t items = (int64_t)a.B * nseg * a.Wo;
+  auto fma_row = [&](float (&acc)[8], const Row8& r, int kh) {
+    const float* w0 = wl + (kh * 3 + 0) * a.C + c0;
+    const float* w1 = wl + (kh * 3 + 1) * a.C + c0;
+    const float* w2 = wl + (kh * 3 + 2) * a.C + c0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaf(r.l[j], w0[j], fmaf(r.c[j], w1[j], fmaf(r.r[j], w2[j], acc[j])));
+  };
+  for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+    const int wo = (int)(it % a.Wo), sg = (int)((it / a.Wo) % nseg), b = (int)(it / ((int64_t)a.Wo * nseg));
+    const int h0 = sg * DWB_SEG, h1 = h0 + DWB_SEG < a.Ho ? h0 + DWB_SEG : a.Ho;
+    const int wi = wo * STRIDE;
+    Row8 r0, r1, r2;
+    dwb_load_row(a, b, h0 * STRIDE - 1, wi, c0, r0);
+    if (STRIDE == 1) dwb_load_row(a, b, h0, wi, c0, r1);
+    for (int ho = h0; ho < h1; ++ho) {
+      if (STRIDE == 2) dwb_load_row(a, b, 2 * ho, wi, c0, r1);
+      dwb_load_row(a, b, ho * STRIDE + 1, wi, c0, r2);
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      fma_row(acc, r0, 0);
+      fma_row(acc, r1, 1);
+      fma_row(acc, r2, 2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = kd_act(kd_affine(acc[j], sc[j], sh[j]), a.act);
+      st16(a.y + (((int64_t)b * a.Ho + ho) * a.Wo + wo) * a.C + c0, pack8(acc));
+      if (STRIDE == 1) { r0 = r1; r1 = r2; } else { r0 = r2; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1x1 convolution as a bf16 GEMM, weight-resident streaming form.  C[m][n] = act((A[m][:] . W[n][:] + bias[n]) * esc[n] +
+// esh[n]) (+ res[m][n]).  AIN 0: A bf16 [M][lda]; 1: A fp32 [M][lda] rounded to bf16 on load (LiDAR BEV grid);
+// 3: A = act0(bn0(layer0(point))) computed from the 16-byte point (LiDAR layer 0, K = 64).  EPI 0: bf16 store;
+// EPI 4: BEV scatter-max of the (non-negative) result into an fp32 grid by the unsigned bit pattern (cell index per row).
+struct GemmBfArgs {
+  const void* A; int64_t lda;
+  const float* W; const float* bias; const float* esc; const float* esh; int act;
+  bf16_t* C; int64_t ldc; const bf16_t* res; int64_t ldres;
+  int64_t M; int K, N;
+  const int* m_dev;
+  const float* l0w; const float* l0b; const float* sc0; const float* sh0; int act0;     // AIN 3
+  const int* cell; float* grid; int64_t ldgrid;                                         // EPI 4
+};
+
+constexpr int BW = 8;                 // waves per workgroup
+
+__device__ __forceinline__ float xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+template <int NB, int AIN, int EPI>
+__global__ __launch_bounds__(64 * BW, 2) void pw_gemm_bf16_kernel(GemmBfArgs g) {
+  constexpr int N = 32 * NB, CH = 8;                                  // CH: k-steps (of 16) per register chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Wh = reinterpret_cast<bf16_t*>(smem_raw);                   // [N][K] bf16, 16-byte chunks swizzled
+  float* Co = reinterpret_cast<float*>(smem_raw + (size_t)N * g.K * 2);  // AIN 3: [7][K]
+  const int K = g.K, CPR = K / 8, NU = K / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const bool odd = (lane & 1) != 0;
+  const int n0 = blockIdx.y * N;
+  auto swz = [&](int n) { return CPR % 16 == 0 ? (n & 15) : (CPR % 16 == 8 ? ((n >> 1) & 7) : ((n >> 2) & 3)); };
+  for (int i = tid; i < N * K / 4; i += 64 * BW) {
+    const int n = i / (K / 4), k4 = i % (K / 4);
+    const float4 w = kd_ld4(g.W + (int64_t)(n0 + n) * K + k4 * 4);
+    bf16_t* d = Wh + n * K + ((k4 >> 1) ^ swz(n)) * 8 + (k4 & 1) * 4;
+    *reinterpret_cast<uint2*>(d) = make_uint2(pk_bf16(w.x, w.y), pk_bf16(w.z, w.w));
+  }
+  if (AIN == 3) {
+    for (int k = tid; k < K; k += 64 * BW) {
+      Co[k] = g.sc0[k]; Co[K + k] = g.sh0[k];
+      const float4 w0 = kd_ld4(g.l0w + k * 4);
+      Co[2 * K + k] = w0.x; Co[3 * K + k] = w0.y; Co[4 * K + k] = w0.z; Co[5 * K + k] = w0.w;
+      Co[6 * K + k] = g.l0b[k];
+    }
+  }
+  kd_lds_barrier();
+
+  int64_t M = g.M;
+  if (g.m_dev) { const int mv = *g.m_dev; M = mv < g.M ? mv : g.M; }
+  const int64_t nslab = (M + 31) / 32;
+  const int64_t wtot = (int64_t)gridDim.x * BW, wid = (int64_t)blockIdx.x * BW + wave;
+  const int fsw = h ^ swz(r);
+
+  float bias[NB], esc[NB], esh[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int c = n0 + 32 * j + r;
+    bias[j] = g.bias ? g.bias[c] : 0.f;
+    esc[j] = g.esc[c]; esh[j] = g.esh[c];
+  }
+
+  // A fragment of k-step u for this lane: 8 consecutive k of row r starting at 16 u + 8 h
+  auto load_frag = [&](int64_t gm, int u) -> u32x4 {
+    if (AIN == 0) {
+      return ld16(reinterpret_cast<const bf16_t*>(g.A) + gm * g.lda + 16 * u + 8 * h);
+    } else if (AIN == 1) {
+      const float* p = reinterpret_cast<const float*>(g.A) + gm * g.lda + 16 * u + 8 * h;
+      const float4 a = kd_ld4(p), b = kd_ld4(p + 4);
+      return u32x4{pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w)};
+    } else {
+      return u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto l0_frag = [&](float4 pt, int u) -> u32x4 {                    // AIN 3: layer 0 + BatchNorm + activation of the point
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int kb = 16 * u + 8 * h + 4 * e;
+      const float4 sc = kd_ld4(Co + kb), sh = kd_ld4(Co + K + kb), wx = kd_ld4(Co + 2 * K + kb), wy = kd_ld4(Co + 3 * K + kb),
+                   wz = kd_ld4(Co + 4 * K + kb), ww = kd_ld4(Co + 5 * K + kb), b0 = kd_ld4(Co + 6 * K + kb);
+      v[4 * e + 0] = kd_act(kd_affine(kd_l0_raw(pt, make_float4(wx.x, wy.x, wz.x, ww.x), b0.x), sc.x, sh.x), g.act0);
+      v[4 * e + 1] = kd_act(kd_affine(kd_l0_raw(pt, make_float4(wx.y, wy.y, wz.y, ww.y), b0.y), sc.y, sh.y), g.act0);
+      v[4 * e + 2] = kd_act(kd_affine(kd_l0_raw(pt, make_float4(wx.z, wy.z, wz.z, ww.z), b0.z), sc.z, sh.z), g.act0);
+      v[4 * e + 3] = kd_act(kd_affine(kd_l0_raw(pt, make_float4(wx.w, wy.w, wz.w, ww.w), b0.w), sc.w, sh.w), g.act0);
+    }
+    return pack8(v);
+  };
+
+  for (int64_t s = wid; s < nslab; s += wtot) {
+    const int64_t m0 = s * 32;
+    int64_t gm = m0 + r;
+    gm = gm < M ? gm : M - 1;
+    float4 pt = kd_zero4();
+    if (AIN == 3) pt = kd_ld4(reinterpret_cast<const float*>(g.A) + gm * 4);
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    // k-loop in chunks of CH k-steps: the next chunk's fragments are requested before the current chunk is multiplied
+    u32x4 cur[CH], nxt[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) cur[i] = (AIN != 3 && i < NU) ? load_frag(gm, i) : u32x4{0u, 0u, 0u, 0u};
+    for (int u0 = 0; u0 < NU; u0 += CH) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) nxt[i] = (AIN != 3 && u0 + CH + i < NU) ? load_frag(gm, u0 + CH + i) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int u = u0 + i;
+        if (u < NU) {
+          const u32x4 af = AIN == 3 ? l0_frag(pt, u) : cur[i];
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const u32x4 bf = *reinterpret_cast<const u32x4*>(Wh + (32 * j + r) * K + ((2 * u) ^ fsw) * 8);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[j], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) cur[i] = nxt[i];
+    }
+    // ---- epilogue: register q of a block is row (q & 3) + 8 (q >> 2) + 4 h, column r ------------------------------------
+    if (EPI == 0) {
+      // neighbouring lanes swap one value of each register pair so that a lane holds two adjacent columns of one row and
+      // stores them as one dword (2 bf16): even lane -> (row R, cols c, c + 1), odd lane -> (row R + 1, cols c - 1, c)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+          const int rbase = (q & 3) + 8 * (q >> 2);
+          float v0 = kd_act(kd_affine(acc[j][q] + bias[j], esc[j], esh[j]), g.act);
+          float v1 = kd_act(kd_affine(acc[j][q + 1] + bias[j], esc[j], esh[j]), g.act);
+          float x0 = xor1(v0), x1 = xor1(v1);
+          asm volatile("" : "+v"(x0), "+v"(x1));                      // keep both DPP moves out of the divergent selects below
+          float lo = odd ? x1 : v0, hi = odd ? v1 : x0;
+          const int64_t row = m0 + rbase + 4 * h + (odd ? 1 : 0);
+          const int col = n0 + 32 * j + (r & ~1);
+          if (row < M) {
+            if (g.res) {
+              const uint32_t rr = *reinterpret_cast<const uint32_t*>(g.res + row * g.ldres + col);
+              lo += bf_lo(rr); hi += bf_hi(rr);
+            }
+            *reinterpret_cast<uint32_t*>(g.C + row * g.ldc + col) = pk_bf16(lo, hi);
+          }
+        }
+      }
+    } else {
+      // EPI 4: scatter-max.  Rows arrive sorted by cell, and registers q = 4 g .. 4 g + 3 of a lane are 4 consecutive rows:
+      // a run of equal cells inside the quad is merged in registers before it touches the grid.
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        int cellv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t row = m0 + 8 * gq + 4 * h + i;
+          cellv[i] = row < M ? g.cell[row] : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          float run = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = kd_act(kd_affine(acc[j][4 * gq + i] + bias[j], esc[j], esh[j]), g.act);
+            const bool first = i == 0 || cellv[i] != cellv[i > 0 ? i - 1 : 0];
+            const bool last = i == 3 || cellv[i] != cellv[i < 3 ? i + 1 : i];
+            run = (first || v > run) ? v : run;
+            if (last && cellv[i] >= 0 && run > 0.f)
+              atomicMax(reinterpret_cast<unsigned*>(g.grid + (int64_t)cellv[i] * g.ldgrid + n0 + 32 * j + r), __float_as_uint(run));
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FPN sum: out = sum_i bilinear_resize(in_i) (align_corners = False; identity when sizes match), up to 3 bf16 inputs.
+struct BlBfArgs {
+  const bf16_t* in[3]; int Hi[3], Wi[3]; float sh[3], sw[3]; int nin;
+  bf16_t* out; int B, Ho, Wo, C, groups, slots;
+};
+__device__ __forceinline__ void bl_src(int o, int in_size, float scale, int& i0, int& i1, float& l0, float& l1) {
+  float src = scale * ((float)o + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+__global__ __launch_bounds__(256) void bilinear_sum_bf16_kernel(BlBfArgs a) {
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  if (slot >= a.slots) return;
+  const int c0 = gidx * 8;
+  const int64_t npix = (int64_t)a.B * a.Ho * a.Wo;
+  for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < npix; p += (int64_t)gridDim.x * a.slots) {
+    const int wo = (int)(p % a.Wo), ho = (int)((p / a.Wo) % a.Ho), b = (int)(p / ((int64_t)a.Wo * a.Ho));
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < a.nin; ++t) {
+      int h0, h1, w0, w1;
+      float lh0, lh1, lw0, lw1;
+      bl_src(ho, a.Hi[t], a.sh[t], h0, h1, lh0, lh1);
+      bl_src(wo, a.Wi[t], a.sw[t], w0, w1, lw0, lw1);
+      const bf16_t* base = a.in[t] + (int64_t)b * a.Hi[t] * a.Wi[t] * a.C + c0;
+      float v00[8], v01[8], v10[8], v11[8];
+      unpack8(ld16(base + ((int64_t)h0 * a.Wi[t] + w0) * a.C), v00);
+      unpack8(ld16(base + ((int64_t)h0 * a.Wi[t] + w1) * a.C), v01);
+      unpack8(ld16(base + ((int64_t)h1 * a.Wi[t] + w0) * a.C), v10);
+      unpack8(ld16(base + ((int64_t)h1 * a.Wi[t] + w1) * a.C), v11);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += lh0 * (lw0 * v00[j] + lw1 * v01[j]) + lh1 * (lw0 * v10[j] + lw1 * v11[j]);
+    }
+    st16(a.out + p * a.C + c0, pack8(acc));
+  }
+}
+
+// classifier: logits[b][nc][hw] = x[m][:] . w[nc][:] + bias[nc]  (x bf16 [M][Cin], Cin <= 64, NC <= 4) -> fp32 NCHW
+__global__ __launch_bounds__(256) void cls_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ logits, int64_t M, int HW, int Cin, int NC) {
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < Cin; c += 8) {
+      float v[8];
+      unpack8(ld16(x + m * Cin + c), v);
+      for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[nc] = fmaf(v[j], w[nc * Cin + c + j], acc[nc]);
+    }
+    const int64_t b = m / HW, hw = m % HW;
+    for (int nc = 0; nc < NC; ++nc) logits[(b * NC + nc) * HW + hw] = acc[nc] + bias[nc];
+  }
+}
+
+int cg8_layout(int64_t rows, int C, int& groups, int& slots) {
+  groups = C / 8;
+  slots = 256 / groups;
+  if (slots < 1) slots = 1;
+  int64_t need = (rows + slots - 1) / slots;
+  return (int)(need < 2048 ? (need < 1 ? 1 : need) : 2048);
+}
+
+template <int NB>
+int launch_gemm_bf16(GemmBfArgs& g, int ain, int epi, hipStream_t st) {
+  const int ntiles = g.N / (32 * NB);
+  int64_t want = (g.M + 32 * BW - 1) / (32 * BW);
+  int cap = 256 / ntiles; if (cap < 1) cap = 1;
+  const dim3 grid((unsigned)(want < cap ? want : cap), ntiles);
+  const size_t lds = (size_t)32 * NB * g.K * 2 + (ain == 3 ? (size_t)7 * g.K * 4 : 0);
+#define KD_BCASE(A_, E_)                                                                                               \
+  if (ain == A_ && epi == E_) {                                                                                        \
+    (void)hipFuncSetAttribute((const void*)pw_gemm_bf16_kernel<NB, A_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((pw_gemm_bf16_kernel<NB, A_, E_>), grid, dim3(64 * BW), lds, st, g);                            \
+    return kd_check_launch("kd_bf16_pwconv");                                                                          \
+  }
+  KD_BCASE(0, 0) KD_BCASE(1, 0) KD_BCASE(3, 0) KD_BCASE(0, 4)
+#undef KD_BCASE
+  kd_set_error("kd_bf16_pwconv: unsupported (input kind %d, epilogue %d)", ain, epi);
+  return KD_ERR_ARG;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kd_bf16_stem(const float* x_nchw, const float* w, const float* sc, const float* sh, int act, void* y, int B, int Cin, int H,
+                 int W, int Cout, void* stream) {
+  KD_REQUIRE(x_nchw && w && sc && sh && y && B > 0 && Cout == 32 && Cin >= 1 && Cin <= 4, KD_ERR_ARG, "kd_bf16_stem: bad args");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  int64_t grid = (npix + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(stem_bf16_kernel, dim3((unsigned)grid), dim3(256), (size_t)Cin * 9 * 32 * sizeof(float), (hipStream_t)stream, x_nchw, w, sc,
+                     sh, act, (bf16_t*)y, B, Cin, H, W, Ho, Wo);
+  return kd_check_launch("kd_bf16_stem");
+}
+
+int kd_bf16_dwconv3x3(const void* x, const float* w, const float* sc, const float* sh, int act, void* y, int B, int H, int W,
+                      int C, int stride, void* stream) {
+  KD_REQUIRE(x && w && sc && sh && y && B > 0 && C % 8 == 0 && C <= 1024 && (stride == 1 || stride == 2), KD_ERR_ARG, "kd_bf16_dwconv3x3: bad args");
+  KD_REQUIRE(kd_aligned16(x) && kd_aligned16(y), KD_ERR_ALIGN, "kd_bf16_dwconv3x3: alignment");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  int groups, slots;
+  const int grid = cg8_layout((int64_t)B * ((Ho + DWB_SEG - 1) / DWB_SEG) * Wo, C, groups, slots);
+  DwBfArgs a{(const bf16_t*)x, w, sc, sh, act, (bf16_t*)y, B, H, W, C, Ho, Wo, stride, groups, slots};
+  const size_t lds = (size_t)C * 9 * sizeof(float);
+  if (stride == 1) hipLaunchKernelGGL(dw_bf16_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(dw_bf16_kernel<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  return kd_check_launch("kd_bf16_dwconv3x3");
+}
+
+/* 1x1 convolution / Conv1d(k=1) + eval BatchNorm + activation (+ residual) on bf16 activations.  a_kind 0: A bf16,
+ * 1: A fp32 (rounded on load), 3: A = LiDAR points [M,4] with layer 0 (l0w [K][4], l0b, sc0, sh0, act0) recomputed.
+ * epi 0: C bf16 [M][ldc] (+ res bf16); epi 4: scatter-max into the fp32 `grid` [cells][ldgrid] by `cell[m]` (rows < 0 skipped;
+ * the caller zero-fills the grid; the activation must be non-negative). */
+int kd_bf16_pwconv(const void* A, int64_t lda, int a_kind, const float* W, const float* bias, const float* esc, const float* esh,
+                   int act, void* C, int64_t ldc, const void* res, int64_t ldres, int epi, int64_t M, int K, int N,
+                   const int* m_dev, const float* l0w, const float* l0b, const float* sc0, const float* sh0, int act0,
+                   const int* cell, float* grid, int64_t ldgrid, void* stream) {
+  KD_REQUIRE(A && W && esc && esh && M > 0 && K >= 16 && N >= 32, KD_ERR_ARG, "kd_bf16_pwconv: bad args");
+  KD_REQUIRE(K % 32 == 0 && (K / 8) % 4 == 0 && N % 32 == 0 && K <= 1024, KD_ERR_SHAPE, "kd_bf16_pwconv: K=%d must be a multiple of 32, N=%d of 32", K, N);
+  KD_REQUIRE(a_kind == 3 || (lda % (a_kind == 0 ? 8 : 4) == 0 && kd_aligned16(A)), KD_ERR_ALIGN, "kd_bf16_pwconv: A alignment");
+  KD_REQUIRE(epi == 4 ? (cell && grid && (act == KD_ACT_RELU || act == KD_ACT_RELU6)) : (C != nullptr && ldc % 2 == 0 && (!res || ldres % 2 == 0)), KD_ERR_ARG,
+             "kd_bf16_pwconv: epilogue arguments");
+  KD_REQUIRE(a_kind != 3 || (l0w && l0b && sc0 && sh0 && K % 4 == 0), KD_ERR_ARG, "kd_bf16_pwconv: layer-0 arguments");
+  GemmBfArgs g{A, lda, W, bias, esc, esh, act, (bf16_t*)C, ldc, (const bf16_t*)res, ldres, M, K, N, m_dev, l0w, l0b, sc0, sh0, act0,
+               cell, grid, ldgrid};
+  hipStream_t st = (hipStream_t)stream;
+  // widest column tile whose W image (32 NB x K bf16) fits beside the coefficient tables in 96 KB of LDS
+  const size_t budget = 96 * 1024;
+  if (N % 128 == 0 && (size_t)128 * K * 2 <= budget) return launch_gemm_bf16<4>(g, a_kind, epi, st);
+  if (N % 64 == 0 && (size_t)64 * K * 2 <= budget) return launch_gemm_bf16<2>(g, a_kind, epi, st);
+  return launch_gemm_bf16<1>(g, a_kind, epi, st);
+}
+
+int kd_bf16_bilinear_sum(const void* in0, int H0, int W0, const void* in1, int H1, int W1, const void* in2, int H2, int W2,
+                         void* out, int B, int Ho, int Wo, int C, void* stream) {
+  KD_REQUIRE(in0 && out && B > 0 && C % 8 == 0 && C <= 2048, KD_ERR_ARG, "kd_bf16_bilinear_sum: bad args");
+  BlBfArgs a{};
+  const void* ins[3] = {in0, in1, in2};
+  const int hs[3] = {H0, H1, H2}, wsz[3] = {W0, W1, W2};
+  a.nin = 0;
+  for (int t = 0; t < 3; ++t)
+    if (ins[t]) {
+      a.in[a.nin] = (const bf16_t*)ins[t]; a.Hi[a.nin] = hs[t]; a.Wi[a.nin] = wsz[t];
+      a.sh[a.nin] = (float)hs[t] / (float)Ho; a.sw[a.nin] = (float)wsz[t] / (float)Wo;
+      ++a.nin;
+    }
+  a.out = (bf16_t*)out; a.B = B; a.Ho = Ho; a.Wo = Wo; a.C = C;
+  const int grid = cg8_layout((int64_t)B * Ho * Wo, C, a.groups, a.slots);
+  hipLaunchKernelGGL(bilinear_sum_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  return kd_check_launch("kd_bf16_bilinear_sum");
+}
+
+int kd_bf16_cls_conv(const void* x, const float* w, const float* b, float* logits_nchw, int64_t M, int HW, int Cin, int NC, void* stream) {
+  KD_REQUIRE(x && w && b && logits_nchw && M > 0 && Cin % 8 == 0 && Cin <= 64 && NC >= 1 && NC <= 4, KD_ERR_ARG, "kd_bf16_cls_conv: bad args");
+  int64_t grid = (M + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cls_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, b, logits_nchw, M, HW, Cin, NC);
+  return kd_check_launch("kd_bf16_cls_conv");
+}
+
+}  // extern "C"

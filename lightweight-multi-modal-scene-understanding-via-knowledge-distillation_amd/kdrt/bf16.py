@@ -1,0 +1,149 @@
+"""bf16-storage inference path (BASELINE.json configs[1]: camera + LiDAR concat-fusion forward in bf16).
+
+A second, separately gated mode beside the fp32 contract: eval-mode forward only.  Activations live in HBM as bf16 NHWC
+matrices, already normalised and activated (in eval mode every unit is ONE kernel: conv -> BatchNorm -> activation
+[+ residual] -> bf16); accumulation is fp32; parameters and BatchNorm buffers stay the model's fp32 tensors.  The kernels are
+csrc/kd_bf16.hip (C ABI `kd_bf16_*`).  Supported: the multiscale TwinLite encoder + FPN, the spatial LiDAR encoder, concat
+and minimal fusion, the same-resolution head -- what `train_with_fusion_ablation.py` builds (weighted fusion's attention
+tail has no bf16 kernel yet and raises).  Accuracy is that of 8-bit-mantissa activations; tests/test_gpu_bf16.py states the
+measured logit error and argmax agreement against the fp32 path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops, units
+from .lib import KDError, lib
+from .ops import ACT_RELU, ACT_RELU6, P, stream
+
+
+def _coef(spec):
+    C = spec.bn.running_mean.numel()
+    return units._coeffs(spec, None, 0, C, 0, False, None, spec.bn.running_mean.device)
+
+
+def _pw(x, spec, M, res=None, out=None, a_kind=0, m_dev=None):
+    """x: bf16 [M, K] (or fp32 when a_kind == 1) -> bf16 [M, N] = act(bn(x . W^T + b)) (+ res)."""
+    w, b = spec.conv.weight, spec.conv.bias
+    N, K = w.shape[0], w.shape[1]
+    bnc = _coef(spec)
+    if out is None:
+        out = torch.empty(M, N, device=w.device, dtype=torch.bfloat16)
+    lib.call("kd_bf16_pwconv", P(x), x.stride(0), a_kind, P(w), P(b), P(bnc.scale), P(bnc.shift), spec.act, P(out), out.stride(0),
+             P(res), res.stride(0) if res is not None else 0, 0, M, K, N, P(m_dev), None, None, None, None, 0, None, None, 0, stream())
+    return out
+
+
+def _dw(x, spec, geom):
+    B, H, W = geom
+    C = x.shape[1]
+    s = spec.stride
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    bnc = _coef(spec)
+    y = torch.empty(B * Ho * Wo, C, device=x.device, dtype=torch.bfloat16)
+    lib.call("kd_bf16_dwconv3x3", P(x), P(spec.conv.weight), P(bnc.scale), P(bnc.shift), spec.act, P(y), B, H, W, C, s, stream())
+    return y, (B, Ho, Wo)
+
+
+def _chain(x, geom, specs, residual=False):
+    cur, g = x, geom
+    for i, u in enumerate(specs):
+        last = i == len(specs) - 1
+        if u.kind == "pw":
+            cur = _pw(cur, u, cur.shape[0], res=x if (last and residual) else None)
+        elif u.kind == "dw":
+            cur, g = _dw(cur, u, g)
+        else:
+            raise KDError(f"bf16 path: unit kind {u.kind!r} is not supported")
+    return cur, g
+
+
+@torch.no_grad()
+def forward_bf16(model, images: torch.Tensor, points: torch.Tensor) -> torch.Tensor:
+    """Eval-mode forward of a CompleteSegmentationModel with bf16 activations; returns fp32 logits [B, C, h, w]."""
+    from src.models.fusion_module import ConcatenationFusion, MinimalFusion, SameResolutionSegmentationHead
+    ops.require_gpu_tensor(images, "forward_bf16")
+    if model.training:
+        raise KDError("forward_bf16 is an inference path: call model.eval() first")
+    enc = model.camera_encoder
+    if not getattr(enc, "return_multiscale", False) or model.camera_fpn is None:
+        raise KDError("bf16 path: needs the multiscale camera encoder + FPN (the training entry points' configuration)")
+    if not isinstance(model.head, SameResolutionSegmentationHead):
+        raise KDError("bf16 path: only the same-resolution head is supported")
+    img = images.contiguous()
+    B, Cin, H, W = img.shape
+    dev = img.device
+    # ---- camera encoder (camera_encoder.py:63-115) ------------------------------------------------------------------------
+    stem = units.UnitSpec("stem", enc.stem[0], enc.stem[1], ACT_RELU6)
+    bnc = _coef(stem)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = torch.empty(B * Ho * Wo, 32, device=dev, dtype=torch.bfloat16)
+    lib.call("kd_bf16_stem", P(img), P(enc.stem[0].weight), P(bnc.scale), P(bnc.shift), ACT_RELU6, P(x), B, Cin, H, W, 32, stream())
+    geom = (B, Ho, Wo)
+    feats = {}
+    for name in ("stage1", "stage2", "stage3", "stage4", "stage5"):
+        blk = getattr(enc, name)
+        x, geom = _chain(x, geom, blk._units(), residual=blk.use_residual)
+        feats[name] = (x, geom)
+    # ---- FPN (fusion_module.py:51-64) -------------------------------------------------------------------------------------------
+    fpn = model.camera_fpn
+    lats = []
+    for s in fpn.stages_to_use:
+        fx, fg = feats[s]
+        lats.append((_pw(fx, fpn.laterals[s].unit(), fx.shape[0]), fg))
+    if len(lats) > 3:
+        raise KDError("bf16 path: at most three FPN stages")
+    Hm, Wm = fpn.target_size if fpn.target_size is not None else max(((g[1], g[2]) for _, g in lats), key=lambda hw: hw[0] * hw[1])
+    Ct = lats[0][0].shape[1]
+    fused = torch.empty(B * Hm * Wm, Ct, device=dev, dtype=torch.bfloat16)
+    a = [(P(t), g[1], g[2]) for t, g in lats] + [(None, 0, 0)] * (3 - len(lats))
+    lib.call("kd_bf16_bilinear_sum", a[0][0], a[0][1], a[0][2], a[1][0], a[1][1], a[1][2], a[2][0], a[2][1], a[2][2], P(fused), B, Hm, Wm, Ct,
+             stream())
+    cam, cgeom = _chain(fused, (B, Hm, Wm), fpn.post.units())
+    # ---- LiDAR encoder (lidar_encoder.py:57-99): points sorted by cell, layer 0 recomputed inside the layer-1 GEMM, layer 2
+    # scatter-maxes straight into the fp32 BEV grid (the [points, 128] layer outputs exist only as bf16 / not at all) ----------
+    lenc = model.lidar_encoder.encoder
+    Hg, Wg = lenc.grid_size
+    pts = points.contiguous().view(-1, 4)
+    Bp, Np = points.shape[0], points.shape[1]
+    r = lenc.point_cloud_range
+    rng = (float(r[0]), float(r[3]), float(r[1]), float(r[4]))
+    if Hg * Wg + 1 > units.SORT_MAX_BINS:
+        raise KDError("bf16 path: BEV grids above 192 x 192 cells are not supported")
+    spts, cell, seg_start = units.sort_points(pts, Bp, Np, Hg, Wg, rng)
+    counter = seg_start[Bp * Hg * Wg:]
+    u0, u1, u2 = lenc._units()
+    c0, c1, c2 = _coef(u0), _coef(u1), _coef(u2)
+    Mp = Bp * Np
+    K0, N1, N2 = u0.conv.weight.shape[0], u1.conv.weight.shape[0], u2.conv.weight.shape[0]
+    y1 = torch.empty(Mp, N1, device=dev, dtype=torch.bfloat16)
+    lib.call("kd_bf16_pwconv", P(spts), 4, 3, P(u1.conv.weight), P(u1.conv.bias), P(c1.scale), P(c1.shift), u1.act, P(y1), N1, None, 0, 0,
+             Mp, K0, N1, P(counter), P(u0.conv.weight), P(u0.conv.bias), P(c0.scale), P(c0.shift), u0.act, None, None, 0, stream())
+    grid = torch.zeros(Bp * Hg * Wg, N2, device=dev, dtype=torch.float32)
+    lib.call("kd_bf16_pwconv", P(y1), N1, 0, P(u2.conv.weight), P(u2.conv.bias), P(c2.scale), P(c2.shift), u2.act, None, 0, None, 0, 4,
+             Mp, N1, N2, P(counter), None, None, None, None, 0, P(cell), P(grid), N2, stream())
+    if (Hg, Wg) != (cgeom[1], cgeom[2]):
+        raise KDError("bf16 path: the LiDAR grid must match the camera feature map (no resize kernel in this mode)")
+    # ---- fusion (fusion_module.py:242-255) ---------------------------------------------------------------------------------------
+    M = cam.shape[0]
+    fus = model.fusion
+    if isinstance(fus, ConcatenationFusion):
+        uc, ul = fus.camera_proj.unit(), fus.lidar_proj.unit()
+        Cc, Cl = uc.conv.weight.shape[0], ul.conv.weight.shape[0]
+        cat = torch.empty(M, Cc + Cl, device=dev, dtype=torch.bfloat16)
+        _pw(cam, uc, M, out=cat[:, :Cc])
+        _pw(grid, ul, M, out=cat[:, Cc:], a_kind=1)
+        from src.models.fusion_module import _dw_unit, _pw_unit
+        fz, fgeom = _chain(cat, cgeom, [_dw_unit(fus.fuse, 0), _pw_unit(fus.fuse, 3)])
+    elif isinstance(fus, MinimalFusion):
+        t = _pw(cam, fus.cam_proj.unit(), M)
+        fz, fgeom = _pw(grid, fus.lidar_proj.unit(), M, res=t, a_kind=1), cgeom
+    else:
+        raise KDError("bf16 path: weighted fusion is not supported (its attention tail has no bf16 kernel)")
+    # ---- head (fusion_module.py:162-173) -------------------------------------------------------------------------------------------
+    hz, hgeom = _chain(fz, fgeom, model.head.block[0].units() + model.head.block[1].units())
+    cls = model.head.cls
+    NC, Cin_c = cls.weight.shape[0], cls.weight.shape[1]
+    logits = torch.empty(B, NC, hgeom[1], hgeom[2], device=dev, dtype=torch.float32)
+    lib.call("kd_bf16_cls_conv", P(hz), P(cls.weight), P(cls.bias), P(logits), hz.shape[0], hgeom[1] * hgeom[2], Cin_c, NC, stream())
+    return logits
