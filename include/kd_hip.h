@@ -87,6 +87,9 @@ int64_t kd_dwconv_stat_rows(int64_t npix_out, int C);
 int kd_dwconv3x3_fwd(const float* x, const float* sc, const float* sh, int act, const float* w, float* y,
                      float* partial, int B, int H, int W, int C, int stride, void* stream);
 int64_t kd_dwconv_bwd_stat_rows(int64_t npix_in, int C);
+/* form of the stride-1 backward when both gradients are requested: 0 separate data / weight kernels, 1 one fused
+ * column-walk kernel, 2 one fused tile kernel (operands staged once through LDS), 3 (default) chosen by shape */
+int kd_set_dw_bwd_mode(int mode);
 size_t kd_dwconv_bwd_ws_bytes(int64_t npix_out, int C);
 int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const float* be, const float* ga,
                      const float* dsc, const float* dsh, int d_act, const float* x, const float* sc,

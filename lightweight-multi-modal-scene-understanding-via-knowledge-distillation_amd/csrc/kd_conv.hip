@@ -5,6 +5,7 @@
 //               BN stats in the epilogue); backward = transposed stencil + per-channel weight sums.
 #include "kd_common.h"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -450,6 +451,156 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// stride-1 backward, tile form: data gradient + BatchNorm-backward sums + weight gradient with every operand element loaded
+// from HBM / L2 and transformed ONCE.  (In the column-walk kernels above each thread loads and BN-transforms its own left /
+// centre / right neighbours: three times the loads, three times the transform arithmetic, and 250 registers of windows.)
+// A workgroup owns a strip of 16 columns x 64 channels and walks down a row segment; per row it stages, cooperatively,
+//   dyl : the folded dy  (al*mask(D) + be*Y + ga, zero outside the image), ring of 4 rows x 18 columns,
+//   xal : the activated input row and xrl : the raw input row (mask + BatchNorm-backward operand), rings of 2 rows,
+// then thread (column, channel quad) reads its 3x3 dy neighbourhood (data gradient) and the activated input row (weight
+// gradient: input row hi pairs with the dy centres of rows hi+1 / hi / hi-1, see dw_bwd_fused_s1_kernel) from LDS.
+// One barrier per row; registers: 9 taps + 9 weight-gradient accumulators + coefficients.
+constexpr int DT_COLS = 16, DT_CQ = 16, DT_LC = DT_COLS + 2;      // strip columns, float4 channel quads per chunk, staged columns
+__global__ __launch_bounds__(256) void dw_bwd_tile_s1_kernel(DwBwdArgs a, int nrow_slab, int nchunk) {
+  __shared__ __attribute__((aligned(16))) float4 dyl[4][DT_LC][DT_CQ];
+  __shared__ __attribute__((aligned(16))) float4 xal[2][DT_LC][DT_CQ];
+  __shared__ __attribute__((aligned(16))) float4 xrl[2][DT_LC][DT_CQ];
+  __shared__ float red[256 * 4];
+  const int tid = threadIdx.x, tx = tid % DT_CQ, ty = tid / DT_CQ;
+  const int chunk = blockIdx.x % nchunk, srow = blockIdx.x / nchunk;
+  const int c0 = chunk * (DT_CQ * 4) + tx * 4;
+  const bool cok = c0 < a.C;                                         // (C need not be a multiple of 64)
+  const int cc = cok ? c0 : 0;
+  const bool deferred = a.sc != nullptr;
+  float4 al = kd_zero4(), be = kd_zero4(), ga = kd_zero4(), dsc = kd_zero4(), dsh = kd_zero4();
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4(), mean = kd_zero4(), inv = kd_zero4();
+  if (a.al) { al = kd_ld4(a.al + cc); be = kd_ld4(a.be + cc); ga = kd_ld4(a.ga + cc); }
+  if (a.dsc) { dsc = kd_ld4(a.dsc + cc); dsh = kd_ld4(a.dsh + cc); }
+  if (deferred) { sc = kd_ld4(a.sc + cc); sh = kd_ld4(a.sh + cc); }
+  if (a.mean) { mean = kd_ld4(a.mean + cc); inv = kd_ld4(a.invstd + cc); }
+  float4 wf[9];                                                       // flipped taps of the thread's 4 channels
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wf[t] = make_float4(a.w[(cc + 0) * 9 + 8 - t], a.w[(cc + 1) * 9 + 8 - t], a.w[(cc + 2) * 9 + 8 - t], a.w[(cc + 3) * 9 + 8 - t]);
+  float4 wacc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wacc[t] = kd_zero4();
+  float4 s1 = kd_zero4(), s2 = kd_zero4();
+
+  const int nstrip = (a.W + DT_COLS - 1) / DT_COLS, nseg = (a.H + DW_SEG - 1) / DW_SEG;
+  const int64_t items = (int64_t)a.B * nseg * nstrip;
+  // staging roles: element e = tid (and e = 256 + tid for tid < 32) of the 18 x 16 row image
+  const int l0c = tid / DT_CQ, l1c = DT_COLS + tid / DT_CQ;           // staged column of the primary / secondary element
+  const bool two = tid < 2 * DT_CQ;
+  // Staging is split in two so that a row's HBM loads fly during the arithmetic of the row before it: fetch_* issues the raw
+  // loads into registers, commit_* (one iteration later) transforms them and writes the LDS image.
+  struct RawDy { DwRaw e[2]; bool ok[2]; };
+  struct RawX { float4 e[2]; bool ok[2]; };
+  auto fetch_dy = [&](int b, int ho, int w0, RawDy& o) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int lc = k ? l1c : l0c, wo = w0 - 1 + lc;
+      o.ok[k] = cok && ho >= 0 && ho < a.Ho && wo >= 0 && wo < a.Wo;
+      const int hoc = ho < 0 ? 0 : (ho >= a.Ho ? a.Ho - 1 : ho), woc = wo < 0 ? 0 : (wo >= a.Wo ? a.Wo - 1 : wo);
+      const int64_t q = (((int64_t)b * a.Ho + hoc) * a.Wo + woc) * a.C + cc;
+      if (k == 0 || two) { o.e[k].d = kd_ld4(a.D + q); o.e[k].y = kd_ld4((a.al ? a.Y : a.D) + q); }
+    }
+  };
+  auto commit_dy = [&](const RawDy& o, int slot) {
+    dyl[slot][l0c][tx] = dw_dy_finish(a, o.e[0], o.ok[0], al, be, ga, dsc, dsh);
+    if (two) dyl[slot][l1c][tx] = dw_dy_finish(a, o.e[1], o.ok[1], al, be, ga, dsc, dsh);
+  };
+  auto fetch_x = [&](int b, int hi, int w0, RawX& o) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int lc = k ? l1c : l0c, wi = w0 - 1 + lc;
+      o.ok[k] = cok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+      const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
+      if (k == 0 || two) o.e[k] = kd_ld4(a.x + (((int64_t)b * a.H + hic) * a.W + wic) * a.C + cc);
+    }
+  };
+  auto commit_x = [&](const RawX& o, int slot) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k == 1 && !two) break;
+      const int lc = k ? l1c : l0c;
+      const float4 xr = o.e[k];
+      const float4 xa = deferred ? kd_affine_act4(xr, sc, sh, a.act) : xr;
+      const bool ok = o.ok[k];
+      xal[slot][lc][tx] = make_float4(ok ? xa.x : 0.f, ok ? xa.y : 0.f, ok ? xa.z : 0.f, ok ? xa.w : 0.f);
+      xrl[slot][lc][tx] = xr;
+    }
+  };
+  for (int64_t it = srow; it < items; it += nrow_slab) {
+    const int strip = (int)(it % nstrip), sg = (int)((it / nstrip) % nseg), b = (int)(it / ((int64_t)nstrip * nseg));
+    const int w0 = strip * DT_COLS, h0 = sg * DW_SEG, h1 = h0 + DW_SEG < a.H ? h0 + DW_SEG : a.H;
+    RawDy pd, pd2;
+    RawX px;
+    fetch_dy(b, h0 - 1, w0, pd);
+    fetch_dy(b, h0, w0, pd2);
+    __syncthreads();                                                  // the previous item's readers are done with the rings
+    commit_dy(pd, (h0 + 3) & 3);
+    commit_dy(pd2, h0 & 3);
+    fetch_dy(b, h0 + 1, w0, pd);
+    fetch_x(b, h0, w0, px);
+    for (int hi = h0; hi < h1; ++hi) {
+      commit_dy(pd, (hi + 1) & 3);
+      commit_x(px, hi & 1);
+      fetch_dy(b, hi + 2, w0, pd);                                    // in flight during this row's arithmetic
+      fetch_x(b, hi + 1, w0, px);
+      __syncthreads();                                                // ring depth 4 / 2: one barrier per row is enough
+      const int lc = ty + 1, wi = w0 + ty;
+      const float4 (*r0)[DT_CQ] = dyl[(hi + 3) & 3], (*r1)[DT_CQ] = dyl[hi & 3], (*r2)[DT_CQ] = dyl[(hi + 1) & 3];
+      const float4 d0l = r0[lc - 1][tx], d0c = r0[lc][tx], d0r = r0[lc + 1][tx];
+      const float4 d1l = r1[lc - 1][tx], d1c = r1[lc][tx], d1r = r1[lc + 1][tx];
+      const float4 d2l = r2[lc - 1][tx], d2c = r2[lc][tx], d2r = r2[lc + 1][tx];
+      const float4 xl = xal[hi & 1][lc - 1][tx], xc = xal[hi & 1][lc][tx], xrr = xal[hi & 1][lc + 1][tx], xr = xrl[hi & 1][lc][tx];
+#define KD_FMA4(ACC, A_, B_) ACC.x = fmaf(A_.x, B_.x, ACC.x); ACC.y = fmaf(A_.y, B_.y, ACC.y); ACC.z = fmaf(A_.z, B_.z, ACC.z); ACC.w = fmaf(A_.w, B_.w, ACC.w);
+      // weight gradient (same pairing and order as dw_bwd_fused_s1_kernel)
+      KD_FMA4(wacc[0], d2c, xl) KD_FMA4(wacc[1], d2c, xc) KD_FMA4(wacc[2], d2c, xrr)
+      KD_FMA4(wacc[3], d1c, xl) KD_FMA4(wacc[4], d1c, xc) KD_FMA4(wacc[5], d1c, xrr)
+      KD_FMA4(wacc[6], d0c, xl) KD_FMA4(wacc[7], d0c, xc) KD_FMA4(wacc[8], d0c, xrr)
+      // data gradient: same fma nesting as dw_fma_row (r, then c, then l; rows 0, 1, 2)
+      float4 acc = kd_zero4();
+      KD_FMA4(acc, d0r, wf[2]) KD_FMA4(acc, d0c, wf[1]) KD_FMA4(acc, d0l, wf[0])
+      KD_FMA4(acc, d1r, wf[5]) KD_FMA4(acc, d1c, wf[4]) KD_FMA4(acc, d1l, wf[3])
+      KD_FMA4(acc, d2r, wf[8]) KD_FMA4(acc, d2c, wf[7]) KD_FMA4(acc, d2l, wf[6])
+#undef KD_FMA4
+      if (cok && wi < a.W) {
+        if (deferred) {
+          acc.x *= kd_act_mask(kd_affine(xr.x, sc.x, sh.x), a.act);
+          acc.y *= kd_act_mask(kd_affine(xr.y, sc.y, sh.y), a.act);
+          acc.z *= kd_act_mask(kd_affine(xr.z, sc.z, sh.z), a.act);
+          acc.w *= kd_act_mask(kd_affine(xr.w, sc.w, sh.w), a.act);
+          s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+          s2.x = fmaf(acc.x, (xr.x - mean.x) * inv.x, s2.x);
+          s2.y = fmaf(acc.y, (xr.y - mean.y) * inv.y, s2.y);
+          s2.z = fmaf(acc.z, (xr.z - mean.z) * inv.z, s2.z);
+          s2.w = fmaf(acc.w, (xr.w - mean.w) * inv.w, s2.w);
+        }
+        float* gp = a.gx + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0;
+        if (a.nt) kd_st4_nt(gp, acc); else kd_st4(gp, acc);
+      }
+    }
+  }
+  // ---- per-workgroup partials: slab row `srow`, this chunk's channels (every (row, chunk) pair is written by exactly one
+  // workgroup, zeros included, so the fixed-order slab reductions need no initialisation) ------------------------------------
+  const int cbase = chunk * (DT_CQ * 4);
+  for (int t = 0; t < 11; ++t) {
+    const float4 v = t < 9 ? wacc[t] : (t == 9 ? s1 : s2);
+    __syncthreads();
+    kd_st4(red + tid * 4, v);
+    __syncthreads();
+    if (tid < DT_CQ * 4 && cbase + tid < a.C) {
+      float s = 0.f;
+      for (int yy = 0; yy < DT_COLS; ++yy) s += red[(yy * DT_CQ + tid / 4) * 4 + (tid & 3)];
+      const int c = cbase + tid;
+      if (t < 9) a.wslab[(int64_t)srow * a.C * 9 + c * 9 + t] = s;
+      else if (a.partial) a.partial[((int64_t)srow * 2 + (t - 9)) * a.C + c] = s;
+    }
+  }
+}
+
 // stride-2 data gradient.  Work item = a column of 2x2 input QUADS (b, 8 quad rows, quad column q): the quad with
 // top-left input pixel (2a, 2q) receives from exactly the four outputs (a, q), (a, q+1), (a+1, q), (a+1, q+1):
 //   gx(2a  , 2q  ) = d00 w11                      gx(2a  , 2q+1) = d01 w10 + d00 w12
@@ -626,9 +777,18 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_sw_kernel(DwBwdArgs a) {
 
 }  // namespace
 
-static bool kd_dw_fused_enabled() {     // KD_DW_FUSED=0: the separate data / weight kernels (A/B, tests)
-  static const int on = [] { const char* e = getenv("KD_DW_FUSED"); return (e && e[0] == '0') ? 0 : 1; }();
-  return on != 0;
+// stride-1 backward form: 0 separate data / weight kernels, 1 fused column walk, 2 fused tile form, 3 (default) by shape:
+// measured on an MI355X (tools/bench_dw, 32 frames) the tile form wins on wide maps with many channels (384 ch at 64x64:
+// 283 vs 330 us), ties at 128-256 channels and loses on 32x32 maps (768 ch: 257 vs 238 us).  KD_DW_FUSED / kd_set_dw_bwd_mode.
+static std::atomic<int> g_dw_mode{-1};
+static int kd_dw_fused_mode() {
+  int m = g_dw_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("KD_DW_FUSED");
+    m = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 3;
+    g_dw_mode.store(m, std::memory_order_relaxed);
+  }
+  return m;
 }
 
 extern "C" {
@@ -692,11 +852,17 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
   KD_REQUIRE(!sc || (sh && (!partial || (mean && invstd))), KD_ERR_ARG, "kd_dwconv3x3_bwd: sc needs sh (+mean/invstd for stats)");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
-  if (gx && dw && stride == 1 && kd_dw_fused_enabled()) {      // one pass: data gradient + statistics + weight-gradient partials
+  int dw_mode = kd_dw_fused_mode();
+  if (dw_mode == 3) dw_mode = (C >= 384 && W >= 64) ? 2 : 1;
+  if (gx && dw && stride == 1 && dw_mode != 0) {               // one pass: data gradient + statistics + weight-gradient partials
     const KdCgLayout l = kd_cg_layout((int64_t)B * H * W, C);
     KD_REQUIRE(ws && ws_bytes >= (size_t)l.grid * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,
                 (float*)ws, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
+    if (dw_mode == 2) {                     // tile form: l.grid slab rows (the row count the callers sized their slabs for) x channel chunks
+      const int nchunk = (C + DT_CQ * 4 - 1) / (DT_CQ * 4);
+      hipLaunchKernelGGL(dw_bwd_tile_s1_kernel, dim3((unsigned)l.grid * nchunk), dim3(256), 0, st, a, l.grid, nchunk);
+    } else
     hipLaunchKernelGGL(dw_bwd_fused_s1_kernel, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(fused)");
     if (rc) return rc;
@@ -726,5 +892,8 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
 }
 
 int64_t kd_dwconv_bwd_stat_rows(int64_t npix_in, int C) { return kd_cg_layout(npix_in, C).grid; }
+
+// 0 separate kernels, 1 fused column walk, 2 fused tile form, 3 choose by shape (default); returns the previous mode
+int kd_set_dw_bwd_mode(int mode) { (void)kd_dw_fused_mode(); return g_dw_mode.exchange(mode < 0 ? 0 : (mode > 3 ? 3 : mode)); }
 
 }  // extern "C"

@@ -313,3 +313,40 @@ def test_inverted_residual_non_square(h, w, stride):
     x = torch.randn(2, 32, h, w, generator=torch.Generator().manual_seed(h * 100 + w))
     _compare(m, lambda xx, st: O.inverted_residual(xx, {("." + k): v for k, v in st.items()}, "", 32, 64, stride, 6, True), x,
              seed=h + w)
+
+
+@pytest.mark.parametrize("shape", [(2, 13, 19, 8), (1, 70, 66, 72), (2, 33, 64, 384)])
+def test_dw_stride1_backward_forms_agree(shape):
+    """The three forms of the stride-1 depthwise backward (separate data / weight kernels, fused column walk, fused tile
+    kernel staged through LDS) on odd and tile-crossing shapes: same data gradient bits (identical fma order), weight
+    gradient and BatchNorm-backward sums to rounding."""
+    from kdrt.lib import lib
+    from kdrt.ops import P, stream, workspace
+    B, H, W, C = shape
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    D, Y, x, w = rnd(B * H * W, C), rnd(B * H * W, C), rnd(B * H * W, C), rnd(C, 9)
+    al, be, ga, sc, sh, mean = rnd(C), rnd(C) * 0.1, rnd(C) * 0.1, rnd(C).abs() + 0.5, rnd(C) * 0.2, rnd(C) * 0.1
+    inv = rnd(C).abs() + 0.5
+    outs = []
+    prev = lib.kd_set_dw_bwd_mode(0)
+    try:
+        for mode in (0, 1, 2):
+            lib.kd_set_dw_bwd_mode(mode)
+            rows = lib.kd_dwconv_bwd_stat_rows(B * H * W, C)
+            gx = torch.empty(B * H * W, C, device="cuda")
+            part = torch.full((rows * 2 * C,), float("nan"), device="cuda")
+            dw = torch.empty(C, 9, device="cuda")
+            nbytes = lib.kd_dwconv_bwd_ws_bytes(B * H * W, C)
+            ws = workspace(nbytes, gx.device)
+            lib.call("kd_dwconv3x3_bwd", P(D), P(Y), P(al), P(be), P(ga), None, None, 0, P(x), P(sc), P(sh), 2, P(mean), P(inv), P(w), P(gx),
+                     P(part), P(dw), B, H, W, C, 1, P(ws), nbytes, stream())
+            torch.cuda.synchronize()
+            outs.append((gx, part.view(rows, 2, C).double().sum(0), dw))
+    finally:
+        lib.kd_set_dw_bwd_mode(prev)
+    (g0, p0, w0), (g1, p1, w1), (g2, p2, w2) = outs
+    assert torch.equal(g0, g1) and torch.equal(g0, g2)
+    for p, wv in ((p1, w1), (p2, w2)):
+        assert ((p - p0).abs() / p0.abs().clamp_min(1.0)).max().item() < 1e-5
+        assert ((wv - w0).abs().max() / w0.abs().max()).item() < 2e-5
