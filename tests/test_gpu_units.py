@@ -348,5 +348,5 @@ def test_dw_stride1_backward_forms_agree(shape):
     (g0, p0, w0), (g1, p1, w1), (g2, p2, w2) = outs
     assert torch.equal(g0, g1) and torch.equal(g0, g2)
     for p, wv in ((p1, w1), (p2, w2)):
-        assert ((p - p0).abs() / p0.abs().clamp_min(1.0)).max().item() < 1e-5
+        assert ((p - p0).abs().max() / p0.abs().max()).item() < 1e-5        # fp32 partial sums in a different order
         assert ((wv - w0).abs().max() / w0.abs().max()).item() < 2e-5
