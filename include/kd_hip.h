@@ -214,6 +214,11 @@ int kd_lidar_scatter_max_idx_fwd(const float* y, const float* sc, const float* s
 /* ---- FPN resize, weighted-fusion tail, classifier (fusion_module.py:58-63,115-120,170-173) ----- */
 int kd_bilinear_accum_fwd(const float* in, const float* sc, const float* sh, int act, float* out, int accumulate,
                           int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
+/* the whole FPN sum in one pass: up to three deferred laterals (in_i == NULL: absent, no gaps), bit-identical to
+ * accumulating them one by one with kd_bilinear_accum_fwd */
+int kd_bilinear_sum_fwd(const float* in0, const float* sc0, const float* sh0, int act0, int H0, int W0, const float* in1,
+                        const float* sc1, const float* sh1, int act1, int H1, int W1, const float* in2, const float* sc2,
+                        const float* sh2, int act2, int H2, int W2, float* out, int B, int Ho, int Wo, int C, void* stream);
 int kd_bilinear_bwd(const float* dout, const float* in, const float* sc, const float* sh, int act,
                     const float* mean, const float* invstd, float* gin, float* partial, int B, int Hi, int Wi,
                     int Ho, int Wo, int C, void* stream);

@@ -59,6 +59,52 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(BlArgs a) {
   }
 }
 
+// FPN sum in ONE pass (CameraFPNLite.forward, fusion_module.py:58-63): out = sum_i resize(act_i(in_i * sc_i + sh_i)) over up to
+// three deferred laterals -- the accumulate form above reads and rewrites the [B, Ho, Wo, C] sum once per lateral.  The terms
+// are added in lateral order with the same per-term expression, so the result equals the accumulate form bit for bit.
+struct Bl3Args {
+  const float* in[3]; const float* sc[3]; const float* sh[3]; int act[3]; int Hi[3], Wi[3]; float shh[3], sww[3]; int nin;
+  float* out; int B, Ho, Wo, C, groups, slots;
+};
+__global__ __launch_bounds__(256) void bilinear_sum_fwd_kernel(Bl3Args a) {
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  if (slot >= a.slots) return;
+  const int c0 = gidx * 4;
+  float4 sc[3], sh[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    sc[t] = make_float4(1.f, 1.f, 1.f, 1.f); sh[t] = kd_zero4();
+    if (t < a.nin && a.sc[t]) { sc[t] = kd_ld4(a.sc[t] + c0); sh[t] = kd_ld4(a.sh[t] + c0); }
+  }
+  const int64_t npix = (int64_t)a.B * a.Ho * a.Wo;
+  for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < npix; p += (int64_t)gridDim.x * a.slots) {
+    const int wo = (int)(p % a.Wo), ho = (int)((p / a.Wo) % a.Ho), b = (int)(p / ((int64_t)a.Wo * a.Ho));
+    float4 r = kd_zero4();
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t < a.nin) {
+        int h0, h1, w0, w1;
+        float lh0, lh1, lw0, lw1;
+        bl_src(ho, a.Hi[t], a.shh[t], h0, h1, lh0, lh1);
+        bl_src(wo, a.Wi[t], a.sww[t], w0, w1, lw0, lw1);
+        const float* base = a.in[t] + (int64_t)b * a.Hi[t] * a.Wi[t] * a.C + c0;
+        const float4 v00 = kd_affine_act4(kd_ld4(base + ((int64_t)h0 * a.Wi[t] + w0) * a.C), sc[t], sh[t], a.act[t]);
+        const float4 v01 = kd_affine_act4(kd_ld4(base + ((int64_t)h0 * a.Wi[t] + w1) * a.C), sc[t], sh[t], a.act[t]);
+        const float4 v10 = kd_affine_act4(kd_ld4(base + ((int64_t)h1 * a.Wi[t] + w0) * a.C), sc[t], sh[t], a.act[t]);
+        const float4 v11 = kd_affine_act4(kd_ld4(base + ((int64_t)h1 * a.Wi[t] + w1) * a.C), sc[t], sh[t], a.act[t]);
+        float4 v;
+        v.x = lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x);
+        v.y = lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y);
+        v.z = lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z);
+        v.w = lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
+        if (t == 0) r = v; else { r.x = v.x + r.x; r.y = v.y + r.y; r.z = v.z + r.z; r.w = v.w + r.w; }
+      }
+    }
+    kd_st4(a.out + p * a.C + c0, r);
+  }
+}
+
 __device__ __forceinline__ float bl_weight(int o, int i, int in_size, float scale) {
   int i0, i1;
   float l0, l1;
@@ -340,6 +386,30 @@ int kd_bilinear_accum_fwd(const float* in, const float* sc, const float* sh, int
            (float)Hi / (float)Ho, (float)Wi / (float)Wo, l.groups, l.slots};
   hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   return kd_check_launch("kd_bilinear_accum_fwd");
+}
+
+// out = sum over up to three deferred laterals of bilinear_resize(act_i(in_i*sc_i+sh_i)), one pass (in_i == NULL: absent).
+int kd_bilinear_sum_fwd(const float* in0, const float* sc0, const float* sh0, int act0, int H0, int W0, const float* in1,
+                        const float* sc1, const float* sh1, int act1, int H1, int W1, const float* in2, const float* sc2,
+                        const float* sh2, int act2, int H2, int W2, float* out, int B, int Ho, int Wo, int C, void* stream) {
+  KD_REQUIRE(in0 && out && B > 0 && C % 4 == 0 && C <= 1024, KD_ERR_ARG, "kd_bilinear_sum_fwd: bad args");
+  const KdCgLayout l = kd_cg_layout((int64_t)B * Ho * Wo, C);
+  Bl3Args a{};
+  const float* ins[3] = {in0, in1, in2};
+  const float* scs[3] = {sc0, sc1, sc2};
+  const float* shs[3] = {sh0, sh1, sh2};
+  const int acts[3] = {act0, act1, act2}, hs[3] = {H0, H1, H2}, wsz[3] = {W0, W1, W2};
+  a.nin = 0;
+  for (int t = 0; t < 3; ++t)
+    if (ins[t]) {
+      KD_REQUIRE(t == a.nin, KD_ERR_ARG, "kd_bilinear_sum_fwd: laterals must be given without gaps");
+      a.in[t] = ins[t]; a.sc[t] = scs[t]; a.sh[t] = shs[t]; a.act[t] = acts[t]; a.Hi[t] = hs[t]; a.Wi[t] = wsz[t];
+      a.shh[t] = (float)hs[t] / (float)Ho; a.sww[t] = (float)wsz[t] / (float)Wo;
+      ++a.nin;
+    }
+  a.out = out; a.B = B; a.Ho = Ho; a.Wo = Wo; a.C = C; a.groups = l.groups; a.slots = l.slots;
+  hipLaunchKernelGGL(bilinear_sum_fwd_kernel, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  return kd_check_launch("kd_bilinear_sum_fwd");
 }
 
 // gin = act'(.) * adjoint_resize(dout); partial (rows = kd_rowwise_stat_rows(B*Hi*Wi, C)) gets (sum G, sum G*xhat).

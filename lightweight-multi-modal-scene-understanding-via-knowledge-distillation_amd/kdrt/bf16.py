@@ -7,6 +7,10 @@ csrc/kd_bf16.hip (C ABI `kd_bf16_*`).  Supported: the multiscale TwinLite encode
 and minimal fusion, the same-resolution head -- what `train_with_fusion_ablation.py` builds (weighted fusion's attention
 tail has no bf16 kernel yet and raises).  Accuracy is that of 8-bit-mantissa activations; tests/test_gpu_bf16.py states the
 measured logit error and argmax agreement against the fp32 path.
+
+The KD step can run its frozen TEACHER through this path (`KDStep(..., teacher_storage="bf16")`): the teacher only supplies
+targets (softened logits, two feature maps), no gradient flows through it, so its activations do not need fp32 storage;
+the student's forward, backward and optimiser stay fp32.
 """
 from __future__ import annotations
 
@@ -59,8 +63,10 @@ def _chain(x, geom, specs, residual=False):
 
 
 @torch.no_grad()
-def forward_bf16(model, images: torch.Tensor, points: torch.Tensor) -> torch.Tensor:
-    """Eval-mode forward of a CompleteSegmentationModel with bf16 activations; returns fp32 logits [B, C, h, w]."""
+def forward_bf16(model, images: torch.Tensor, points: torch.Tensor, return_intermediates: bool = False):
+    """Eval-mode forward of a CompleteSegmentationModel with bf16 activations; returns fp32 logits [B, C, h, w].
+    With `return_intermediates` also the two feature maps the KD objective matches (fusion_module.py:260-262's
+    `camera_feat` and `lidar_feat`), as fp32 NCHW-shaped views: (logits, {"camera_feat", "lidar_feat", "logits"})."""
     from src.models.fusion_module import ConcatenationFusion, MinimalFusion, SameResolutionSegmentationHead
     ops.require_gpu_tensor(images, "forward_bf16")
     if model.training:
@@ -146,4 +152,7 @@ def forward_bf16(model, images: torch.Tensor, points: torch.Tensor) -> torch.Ten
     NC, Cin_c = cls.weight.shape[0], cls.weight.shape[1]
     logits = torch.empty(B, NC, hgeom[1], hgeom[2], device=dev, dtype=torch.float32)
     lib.call("kd_bf16_cls_conv", P(hz), P(cls.weight), P(cls.bias), P(logits), hz.shape[0], hgeom[1] * hgeom[2], Cin_c, NC, stream())
+    if return_intermediates:       # the camera map is widened once (layout plumbing); the BEV grid is fp32 already
+        return logits, {"camera_feat": ops.nchw_from_matrix(cam.float(), cgeom), "lidar_feat": ops.nchw_from_matrix(grid, (Bp, Hg, Wg)),
+                        "logits": logits}
     return logits

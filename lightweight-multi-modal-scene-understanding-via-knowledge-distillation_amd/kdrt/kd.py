@@ -19,7 +19,12 @@ from .optim import FusedAdamW
 class KDStep:
     def __init__(self, student, teacher, optimizer: FusedAdamW, class_weights: Optional[torch.Tensor] = None,
                  T: float = 4.0, alpha: float = 1.0, beta: float = 1.0, ignore_index: int = -1,
-                 reducer: Optional[BucketedAllReduce] = None):
+                 reducer: Optional[BucketedAllReduce] = None, teacher_storage: str = "fp32"):
+        if teacher_storage not in ("fp32", "bf16"):
+            raise ValueError(f"teacher_storage must be 'fp32' or 'bf16', got {teacher_storage!r}")
+        # "bf16": the frozen teacher runs kdrt.bf16.forward_bf16 (bf16 activations in HBM, fp32 accumulate); a second,
+        # separately gated mode -- the default keeps every tensor of the step fp32
+        self.teacher_storage = teacher_storage
         self.student, self.teacher, self.opt = student, teacher, optimizer
         self.cw, self.T, self.alpha, self.beta, self.ignore_index = class_weights, T, alpha, beta, ignore_index
         self.reducer = reducer
@@ -28,11 +33,17 @@ class KDStep:
         for p in self.teacher.parameters():
             p.requires_grad_(False)
 
+    def teacher_forward(self, images, points):
+        with torch.no_grad():
+            if self.teacher_storage == "bf16":
+                from .bf16 import forward_bf16
+                return forward_bf16(self.teacher, images, points, return_intermediates=True)
+            return self.teacher(images, points, return_intermediates=True)
+
     def __call__(self, images, points, labels):
         units.share_point_bins(True)       # teacher and student of THIS step sort the same points once ...
         try:
-            with torch.no_grad():
-                zt, mt = self.teacher(images, points, return_intermediates=True)
+            zt, mt = self.teacher_forward(images, points)
             gradsink.active = self.sink
             self.sink.begin_step()
             self.opt.zero_grad()
@@ -79,8 +90,7 @@ class GraphedKDStep:
 
     def _body(self):
         s = self.step
-        with torch.no_grad():
-            zt, mt = s.teacher(self.images, self.points, return_intermediates=True)
+        zt, mt = s.teacher_forward(self.images, self.points)
         gradsink.active = s.sink
         s.sink.begin_step()
         s.opt.zero_grad()

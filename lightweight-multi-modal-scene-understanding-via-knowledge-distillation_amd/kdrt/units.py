@@ -448,10 +448,14 @@ class FPNFn(torch.autograd.Function):
         Ct = lat_ops[0].C
         dev = lat_ops[0].raw.device
         fused = torch.empty(B * Ho * Wo, Ct, device=dev, dtype=torch.float32)
-        for i, op in enumerate(lat_ops):
-            _, Hi, Wi = op.geom
-            lib.call("kd_bilinear_accum_fwd", P(op.raw), P(op.sc), P(op.sh), op.act, P(fused), int(i > 0), B, Hi, Wi,
-                     Ho, Wo, Ct, stream())
+        if len(lat_ops) <= 3:        # the whole sum in one pass (same bits as accumulating lateral by lateral)
+            a = [(P(op.raw), P(op.sc), P(op.sh), op.act, op.geom[1], op.geom[2]) for op in lat_ops] + [(None, None, None, 0, 0, 0)] * (3 - len(lat_ops))
+            lib.call("kd_bilinear_sum_fwd", *a[0], *a[1], *a[2], P(fused), B, Ho, Wo, Ct, stream())
+        else:
+            for i, op in enumerate(lat_ops):
+                _, Hi, Wi = op.geom
+                lib.call("kd_bilinear_accum_fwd", P(op.raw), P(op.sc), P(op.sh), op.act, P(fused), int(i > 0), B, Hi, Wi,
+                         Ho, Wo, Ct, stream())
         cur = Operand(fused, (B, Ho, Wo))
         post_recs = []
         if inference_tail_ok(post_units, infer):

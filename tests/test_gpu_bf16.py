@@ -56,3 +56,43 @@ def test_bf16_mode_is_gated():
         forward_bf16(m2, images.cuda(), pts.cuda())
     with pytest.raises(KDError):                     # MI355X only
         forward_bf16(m2.eval(), images, pts)
+
+
+# KD step with the frozen teacher on the bf16 path.  Measured on an MI355X (below): the teacher's targets move by
+# the bf16 forward error above, so KL and the two feature MSEs move by at most a few per cent and the student's
+# gradient keeps its direction (cosine > 0.999); CE does not involve the teacher and stays bit-identical.
+KD_LOSS_TOL_REL = 5e-2
+KD_GRAD_COS_MIN = 0.995
+
+
+def test_kd_step_with_bf16_teacher():
+    from kdrt.kd import KDStep
+    from kdrt.optim import FusedAdamW
+    B, HW, N, G = 2, 256, 5000, 64
+    images, pts, labels = O.make_inputs(B, HW, N, G, 4, pad_tail=40)
+    images, pts, labels = images.cuda(), pts.cuda(), labels.cuda()
+    cw = torch.tensor([0.4, 3.5]).cuda()
+    res = {}
+    for storage in ("fp32", "bf16"):
+        teacher = build_product("concat", G)
+        load_random_state(teacher, "concat", 11)
+        student = build_product("weighted", G)
+        load_random_state(student, "weighted", 12)
+        student.train()
+        opt = FusedAdamW(student.parameters(), lr=0.0, weight_decay=0.0)     # lr 0: the flat gradient survives the step
+        step = KDStep(student, teacher, opt, cw, T=4.0, alpha=1.0, beta=1.0, teacher_storage=storage)
+        parts = step(images, pts, labels)
+        torch.cuda.synchronize()
+        res[storage] = ({k: parts[k].item() for k in ("ce", "kl", "mse_cam", "mse_lidar", "total")}, opt.flat.grad.clone())
+    (p32, g32), (p16, g16) = res["fp32"], res["bf16"]
+    assert p16["ce"] == p32["ce"]                                            # no teacher in CE
+    for k in ("kl", "mse_cam", "mse_lidar", "total"):
+        rel = abs(p16[k] - p32[k]) / max(abs(p32[k]), 1e-6)
+        print(f"bf16 teacher: {k} {p32[k]:.6f} -> {p16[k]:.6f} ({rel:.2%})")
+        assert rel <= KD_LOSS_TOL_REL, (k, p32[k], p16[k])
+    cos = torch.nn.functional.cosine_similarity(g16.double().view(1, -1), g32.double().view(1, -1)).item()
+    nrm = (g16.double().norm() / g32.double().norm()).item()
+    print(f"bf16 teacher: student gradient cosine {cos:.6f}, norm ratio {nrm:.4f}")
+    assert cos >= KD_GRAD_COS_MIN and abs(nrm - 1) < 5e-2
+    with pytest.raises(ValueError):
+        KDStep(student, teacher, opt, cw, teacher_storage="fp16")

@@ -350,3 +350,28 @@ def test_dw_stride1_backward_forms_agree(shape):
     for p, wv in ((p1, w1), (p2, w2)):
         assert ((p - p0).abs().max() / p0.abs().max()).item() < 1e-5        # fp32 partial sums in a different order
         assert ((wv - w0).abs().max() / w0.abs().max()).item() < 2e-5
+
+
+def test_fpn_sum_single_pass_equals_accumulate():
+    """kd_bilinear_sum_fwd (the FPN sum of fusion_module.py:58-63 in one pass) against lateral-by-lateral
+    kd_bilinear_accum_fwd: the same bits, for 1..3 laterals with mixed geometry and activations."""
+    from kdrt import ops
+    from kdrt.ops import lib, P, stream
+    g = torch.Generator().manual_seed(3)
+    B, Ho, Wo, C = 2, 12, 10, 128
+    geo = [(12, 10), (6, 5), (3, 4)]
+    ins = [torch.randn(B * h * w, C, generator=g).cuda() for h, w in geo]
+    scs = [torch.rand(C, generator=g).cuda() + 0.5 for _ in geo]
+    shs = [torch.randn(C, generator=g).cuda() for _ in geo]
+    acts = [ops.ACT_RELU, ops.ACT_NONE, ops.ACT_RELU]
+    for n in (1, 2, 3):
+        ref = torch.empty(B * Ho * Wo, C, device="cuda")
+        for i in range(n):
+            lib.call("kd_bilinear_accum_fwd", P(ins[i]), P(scs[i]), P(shs[i]), acts[i], P(ref), int(i > 0), B, geo[i][0],
+                     geo[i][1], Ho, Wo, C, stream())
+        a = [(P(ins[i]), P(scs[i]), P(shs[i]), acts[i], geo[i][0], geo[i][1]) for i in range(n)]
+        a += [(None, None, None, 0, 0, 0)] * (3 - n)
+        out = torch.full((B * Ho * Wo, C), float("nan"), device="cuda")
+        lib.call("kd_bilinear_sum_fwd", *a[0], *a[1], *a[2], P(out), B, Ho, Wo, C, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), n
