@@ -57,7 +57,7 @@ int64_t kd_pwconv_stat_rows_for(int64_t M, int K, int N, int pro, int epi);
 /* Rows of the statistics slab the launch for (K, N, pro, epi) will write in the current arithmetic (one per wave for the
  * weight-resident streaming kernels of kd_gemm_stream.hip, one per 128 matrix rows for the tiled kernels): size the slab and
  * drive kd_bn_finalize_train / kd_bn_bwd_finalize with it.  kd_set_gemm_stream: 0 = tiled kernels only, 1 = streaming
- * kernels only for the shapes that win in isolation, 2 = every covered shape (default; env KD_GEMM_STREAM=0|1|all);
+ * kernels only for the shapes that win in isolation, 2 = every covered shape (default; env KD_GEMM_STREAM=0|1|all), 3 = every covered forward shape, tiled data gradients;
  * returns the previous mode. */
 int kd_set_gemm_stream(int mode);
 int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, int pro, int pro_act,
@@ -134,6 +134,10 @@ int kd_lidar_l1_dgrad(const float* G, int64_t ldg, const float* Y1, int64_t ldy,
  * (dW0 = al0 * m1 + sum_m (be0*y0 + ga0) * pts, the second term from kd_lidar_l0_bwd with D = NULL).  With m1_out set,
  * G0 may be NULL and the [points, K0] gradient is never written.  m1_ws: kd_lidar_l1_dgrad_ws_bytes. */
 size_t kd_lidar_l1_dgrad_ws_bytes(int64_t M, int K0);
+/* rows of the BatchNorm-backward slab (`partial`) kd_lidar_l1_dgrad / kd_lidar_l2_dgrad write for a shape in the current
+ * arithmetic (one per wave when a streaming kernel takes the launch, one per 128 matrix rows otherwise) */
+int64_t kd_lidar_l1_dgrad_stat_rows(int64_t M, int N1, int K0);
+int64_t kd_lidar_l2_dgrad_stat_rows(int64_t M, int N2, int K1);
 int kd_lidar_l1_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, int d_act, const float* al,
                       const float* be, const float* ga, const float* msc, const float* msh, const float* pts,
                       const float* w0, const float* b0, const float* sc0, const float* sh0, int act0, float* dW,

@@ -1000,7 +1000,15 @@ int kd_lidar_l1_fwd(const float* pts, const float* w0, const float* b0, const fl
 
 // data gradient: G0[M,K0] = (dy1_eff[M,N1] . W1) * act0'(bn0(l0(pts))) with the BN0-backward sums in `partial`;
 // dy1_eff = al*(G*mask(Y1*msc+msh)) + be*Y1 + ga; Wt = W1 as stored ([N1][K0]) transposed by the caller ([K0][N1]).
-size_t kd_lidar_l1_dgrad_ws_bytes(int64_t M, int K0) { return (size_t)((M + 127) / 128) * 4 * K0 * sizeof(float); }
+// (one slab row per tile of the tiled kernel, or per wave of the streaming kernel: the larger of the two)
+size_t kd_lidar_l1_dgrad_ws_bytes(int64_t M, int K0) {
+  const int64_t tiled = (M + 127) / 128, waves = (M + 31) / 32 < 2048 ? (M + 31) / 32 + 8 : 2048;
+  return (size_t)(tiled > waves ? tiled : waves) * 4 * K0 * sizeof(float);
+}
+// rows of the BatchNorm-backward slab (`partial`, [rows][2][K0]) kd_lidar_l1_dgrad writes for this shape
+int64_t kd_lidar_l1_dgrad_stat_rows(int64_t M, int N1, int K0) { return kd_pwconv_stat_rows_for(M, N1, K0, 2, 3); }
+// ... and kd_lidar_l2_dgrad ([rows][2][K1])
+int64_t kd_lidar_l2_dgrad_stat_rows(int64_t M, int N2, int K1) { return kd_pwconv_stat_rows_for(M, N2, K1, 4, 2); }
 
 // m1_out (optional, [4][K0]) = sum_m G0[m][:] * pts[m][j]: with it (and its workspace m1_ws of
 // kd_lidar_l1_dgrad_ws_bytes) the layer-0 weight gradient needs G0 only through these moments, and G0 may be NULL.
@@ -1020,11 +1028,13 @@ int kd_lidar_l1_dgrad(const float* G, int64_t ldg, const float* Y1, int64_t ldy,
   GemmArgs g{G, ldg, Y1, ldy, al, be, ga, msc, msh, 2, mact, Wt, nullptr, G0, ldg0, nullptr, 0,
              pts, 4, sc0, sh0, mean0, invstd0, act0, partial, (int)M, N1, K0, nullptr, w0, b0,
              nullptr, nullptr, nullptr, m1_out ? (float*)m1_ws : nullptr};
+  const int sr = g_gemm_split.load(std::memory_order_relaxed) ? kd_gemm_stream_stat_rows(M, N1, K0, 2, 3) : 0;
   const int rc = gemm_launch(g, 2, 3, (hipStream_t)stream);
   if (rc || !m1_out) return rc;
-  // one slab row per output tile: 256 rows when the output is at most 64 wide (see gemm_launch), else 128
+  // one slab row per wave of the streaming kernel, else per output tile: 256 rows when the output is at most 64 wide
+  // (see gemm_launch), else 128
   const bool tall = ((K0 - 1) % 128) < 64;
-  const int nrb = (int)(tall ? (M + 255) / 256 : (M + 127) / 128);
+  const int nrb = sr > 0 ? sr : (int)(tall ? (M + 255) / 256 : (M + 127) / 128);
   return kd_slab_reduce_tall_launch((float*)m1_ws, nrb, (int64_t)4 * K0, m1_out, (hipStream_t)stream);
 }
 

@@ -251,7 +251,7 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
             if inp.virt is not None:
                 if addend is not None:
                     raise KDError("addend on a virtual LiDAR layer-0 input is not supported")
-                rows_in = lib.kd_pwconv_stat_rows(M)
+                rows_in = lib.kd_lidar_l1_dgrad_stat_rows(M, N, K)
                 part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
                 if _L0_MOMENTS:
                     # layer 0's weight gradient is linear in G0: the GEMM epilogue leaves sum G0 * point and G0 is never written
@@ -265,13 +265,13 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
                     g_in = ("G", gin, part_in, rows_in)
             elif tables:
                 gin = torch.empty(M, K, device=dev, dtype=torch.float32)
-                rows_in = lib.kd_pwconv_stat_rows(M)
+                rows_in = lib.kd_lidar_l2_dgrad_stat_rows(M, N, K)
                 part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
                 ops.l2_dgrad(t, out_op, Wt, gin, inp=inp, al=al, be=be, ga=ga, partial=part_in)
                 g_in = ("G", gin, part_in, rows_in)
             elif inp.bnc is not None:
                 gin = torch.empty(M, K, device=dev, dtype=torch.float32)
-                rows_in = lib.kd_pwconv_stat_rows(M)
+                rows_in = lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2)     # (reduction width N, output width K: the data gradient)
                 part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
                 ops.pw_gemm(t, Wt, gin, M=M, K=N, N=K, A2=y, pro=2, pro_act=mact, p=(al, be, ga, msc, msh),
                             addend=addend, epi=2, X=inp.raw, esc=inp.sc, esh=inp.sh, emean=inp.bnc.mean,
@@ -351,7 +351,7 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
             Wd = rec.w.view(Cin, N16)                                     # dgrad operand [N = Cin, K = Cout*16] as stored
             if inp.bnc is not None:
                 gin = torch.empty(inp.M, Cin, device=dev, dtype=torch.float32)
-                rows_in = lib.kd_pwconv_stat_rows(inp.M)
+                rows_in = lib.kd_pwconv_stat_rows_for(inp.M, N16, Cin, 0, 2)
                 part_in = torch.empty(rows_in * 2 * Cin, device=dev, dtype=torch.float32)
                 ops.pw_gemm(dcol, Wd, gin, M=inp.M, K=N16, N=Cin, addend=addend, epi=2, X=inp.raw, esc=inp.sc, esh=inp.sh,
                             emean=inp.bnc.mean, einv=inp.bnc.invstd, epi_act=inp.act, partial=part_in)

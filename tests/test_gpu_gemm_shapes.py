@@ -9,7 +9,10 @@ import torch
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_arith")]
 TOL = 2e-5
 
-SHAPES = [(1, 4, 4), (37, 36, 20), (128, 32, 192), (300, 100, 132), (257, 192, 64), (1000, 16, 256), (513, 64, 16), (129, 768, 128)]
+# (the shapes whose K and N are multiples of 32 also run the weight-resident streaming kernels in the split arithmetic:
+# several column tiles, K chunks, tail slabs)
+SHAPES = [(1, 4, 4), (37, 36, 20), (128, 32, 192), (300, 100, 132), (257, 192, 64), (1000, 16, 256), (513, 64, 16), (129, 768, 128),
+          (1000, 64, 384), (777, 128, 128), (2100, 32, 32), (640, 64, 192), (333, 384, 64), (901, 128, 64), (450, 256, 128)]
 
 
 def _act(z, act):
@@ -38,7 +41,7 @@ def test_forward_prologues_and_stats(M, K, N):
         ref_in = A.double() if pro == 0 else _act(A.double() * sc.double() + sh.double(), act)
         want = ref_in @ W.double().t() + (bias.double() if use_bias else 0)
         C = torch.full((M, N + 4), 7.0, device="cuda")[:, :N]         # strided output; the pad must stay untouched
-        rows = ops.lib.kd_pwconv_stat_rows(M)
+        rows = ops.lib.kd_pwconv_stat_rows_for(M, K, N, pro, epi)        # rows the launch for this shape writes
         partial = torch.zeros(rows * 2 * N, device="cuda") if epi else None
         ops.pw_gemm(Ad, W.cuda(), C, M=M, K=K, N=N, pro=pro, pro_act=act, p=(sc.cuda(), sh.cuda(), None, None, None),
                     bias=bias.cuda() if use_bias else None, epi=epi, partial=partial)
@@ -69,7 +72,7 @@ def test_dgrad_and_wgrad(M, K, N):
     dx = (dy @ d(W)) * (zx > 0).double()
     c = lambda t: t.cuda()
     gin = torch.empty(M, K, device="cuda")
-    rows = ops.lib.kd_pwconv_stat_rows(M)
+    rows = ops.lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2)              # (reduction width N, output width K)
     part = torch.zeros(rows * 2 * K, device="cuda")
     Wt = ops.transpose(c(W))                                           # [K][N]
     ops.pw_gemm(c(G), Wt, gin, M=M, K=N, N=K, A2=c(Y), pro=2, pro_act=1, p=(c(al), c(be), c(ga), c(msc), c(msh)), epi=2,
@@ -84,3 +87,117 @@ def test_dgrad_and_wgrad(M, K, N):
     ops.pw_wgrad(c(G), c(X), dW, M=M, N=N, K=K, X=c(Y), d_mode=2, d_act=1, al=c(al), be=c(be), ga=c(ga), msc=c(msc), msh=c(msh),
                  a_mode=1, a_act=1, asc=c(esc), ash=c(esh))
     _close(dW, dy.t() @ aeff, "wgrad")
+
+
+def _both_forms(fn):
+    """Run fn() with the tiled kernels, then with the streaming kernels; returns the two results."""
+    from kdrt import ops
+    prev = ops.lib.kd_set_gemm_stream(0)
+    try:
+        a = fn()
+        ops.lib.kd_set_gemm_stream(2)
+        b = fn()
+    finally:
+        ops.lib.kd_set_gemm_stream(prev)
+    return a, b
+
+
+@pytest.mark.parametrize("M,K,N", [(2100, 32, 32), (640, 64, 192), (777, 128, 128), (1000, 64, 384), (333, 384, 64), (129, 768, 128),
+                                   (450, 256, 128), (5000, 192, 32)])
+@pytest.mark.parametrize("epi,with_addend", [(0, False), (0, True), (2, False), (2, True)])
+def test_streaming_dgrad_same_bits_as_tiled(M, K, N, epi, with_addend):
+    """The streaming form of the data gradient (PRO2 operand from two streamed tensors, K chunks, several column tiles,
+    residual gradient, activation mask + BatchNorm-backward sums) against the tiled kernel: the same bits in the result,
+    the same sums up to summation order.  Split arithmetic only (the exact-fp32 mode has no streaming form)."""
+    from kdrt import ops
+    if ops.get_gemm_arithmetic() != "split":
+        pytest.skip("streaming kernels exist in the split arithmetic only")
+    g = torch.Generator().manual_seed(M + 3 * K + 5 * N + epi)
+    c = lambda t: t.cuda()
+    G, Y, X, add = (c(torch.randn(M, n, generator=g)) for n in (N, N, K, K))
+    Wt = c(torch.randn(K, N, generator=g) / N ** 0.5)
+    al, be, ga, msc, msh = (c(torch.randn(N, generator=g) * 0.5) for _ in range(5))
+    esc, esh, mean, inv = (c(torch.rand(K, generator=g) + 0.5) for _ in range(4))
+
+    def run():
+        rows = ops.lib.kd_pwconv_stat_rows_for(M, N, K, 2, epi)
+        gin = torch.full((M, K), float("nan"), device="cuda")
+        part = torch.zeros(rows * 2 * K, device="cuda") if epi == 2 else None
+        ops.pw_gemm(G, Wt, gin, M=M, K=N, N=K, A2=Y, pro=2, pro_act=2, p=(al, be, ga, msc, msh), addend=add if with_addend else None,
+                    epi=epi, X=X if epi == 2 else None, esc=esc, esh=esh, emean=mean, einv=inv, epi_act=2, partial=part)
+        torch.cuda.synchronize()
+        return gin, (part.view(rows, 2, K).double().sum(0) if epi == 2 else None), rows
+
+    (g0, s0, r0), (g1, s1, r1) = _both_forms(run)
+    assert r1 != r0 or M <= 128, "the streaming kernel did not take this shape"
+    assert torch.equal(g0, g1)
+    if epi == 2:
+        scale = g0.double().abs().sum(0).max().item()
+        assert (s0 - s1).abs().max().item() <= 1e-5 * max(scale, 1.0)
+
+
+def test_streaming_lidar_dgrads_same_bits_as_tiled():
+    """kd_lidar_l2_dgrad (scatter-max gradient rebuilt from the per-cell tables, PRO4) and kd_lidar_l1_dgrad (layer 0
+    recomputed from the points in the epilogue, moments of the layer-0 weight gradient, EPI3): streaming vs tiled."""
+    from kdrt import ops
+    from kdrt.ops import lib, P, stream
+    if ops.get_gemm_arithmetic() != "split":
+        pytest.skip("streaming kernels exist in the split arithmetic only")
+    g = torch.Generator().manual_seed(77)
+    c = lambda t: t.cuda()
+    M, C0, C1, C2, cells = 4133, 64, 128, 128, 300
+    Y2, Y1 = c(torch.randn(M, C2, generator=g)), c(torch.randn(M, C1, generator=g))
+    rows_t = torch.randint(-1, cells, (M,), generator=g, dtype=torch.int32).sort().values.cuda()
+    sc2, sh2 = c(torch.rand(C2, generator=g) + 0.5), c(torch.randn(C2, generator=g) * 0.2)
+    # cell maxima consistent with Y2 so that a fair share of rows hold a maximum
+    v2 = torch.clamp_min(Y2 * sc2 + sh2, 0)
+    grid = torch.zeros(cells, C2, device="cuda")
+    ok = rows_t >= 0
+    grid.index_reduce_(0, rows_t[ok].long(), v2[ok], "amax", include_self=True)
+    share = c(torch.randn(cells, C2, generator=g))
+    al, be, ga = (c(torch.randn(C2, generator=g) * 0.5) for _ in range(3))
+    Wt2 = c(torch.randn(C1, C2, generator=g) / C2 ** 0.5)
+    sc1, sh1, mean1, inv1 = (c(torch.rand(C1, generator=g) + 0.5) for _ in range(4))
+
+    def run_l2():
+        rows = lib.kd_lidar_l2_dgrad_stat_rows(M, C2, C1)
+        G1 = torch.full((M, C1), float("nan"), device="cuda")
+        part = torch.zeros(rows * 2 * C1, device="cuda")
+        lib.call("kd_lidar_l2_dgrad", P(Y2), C2, P(rows_t), P(grid), P(share), P(al), P(be), P(ga), P(sc2), P(sh2), 1, P(Wt2), P(G1), C1,
+                 P(Y1), C1, P(sc1), P(sh1), P(mean1), P(inv1), 1, P(part), M, C2, C1, stream())
+        torch.cuda.synchronize()
+        return G1, part.view(rows, 2, C1).double().sum(0), rows
+
+    (a0, s0, r0), (a1, s1, r1) = _both_forms(run_l2)
+    assert r0 != r1 and torch.equal(a0, a1)
+    assert (s0 - s1).abs().max().item() <= 1e-5 * max(a0.double().abs().sum(0).max().item(), 1.0)
+
+    pts = c(torch.randn(M, 4, generator=g))
+    w0, b0 = c(torch.randn(C0, 4, generator=g) * 0.5), c(torch.randn(C0, generator=g) * 0.1)
+    sc0, sh0, mean0, inv0 = (c(torch.rand(C0, generator=g) + 0.5) for _ in range(4))
+    al1, be1, ga1, msc1, msh1 = (c(torch.randn(C1, generator=g) * 0.5) for _ in range(5))
+    Wt1 = c(torch.randn(C0, C1, generator=g) / C1 ** 0.5)
+    G1 = a0
+
+    def run_l1(store):
+        def fn():
+            rows = lib.kd_lidar_l1_dgrad_stat_rows(M, C1, C0)
+            part = torch.zeros(rows * 2 * C0, device="cuda")
+            m1 = torch.full((4, C0), float("nan"), device="cuda")
+            nbytes = lib.kd_lidar_l1_dgrad_ws_bytes(M, C0)
+            ws = torch.empty(nbytes // 4, device="cuda")
+            G0 = torch.full((M, C0), float("nan"), device="cuda") if store else None
+            lib.call("kd_lidar_l1_dgrad", P(G1), C1, P(Y1), C1, P(al1), P(be1), P(ga1), P(msc1), P(msh1), 1, P(Wt1), P(G0), C0, P(pts), P(w0),
+                     P(b0), P(sc0), P(sh0), P(mean0), P(inv0), 1, P(part), P(m1), P(ws), nbytes, M, C1, C0, stream())
+            torch.cuda.synchronize()
+            return G0, part.view(rows, 2, C0).double().sum(0), m1.double(), rows
+        return fn
+
+    for store in (True, False):
+        (g0, s0, m0, r0), (g1, s1, m1_, r1) = _both_forms(run_l1(store))
+        assert r0 != r1
+        if store:
+            assert torch.equal(g0, g1)
+            scale = g0.double().abs().sum(0).max().item()
+        assert (s0 - s1).abs().max().item() <= 1e-5 * max(scale, 1.0)
+        assert (m0 - m1_).abs().max().item() <= 1e-5 * max(scale, 1.0) * 4
