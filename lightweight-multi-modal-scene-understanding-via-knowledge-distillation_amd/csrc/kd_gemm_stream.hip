@@ -29,7 +29,7 @@ int stream_mode() {          // 0 off, 1 only the forward shapes that win in iso
   return v;
 }
 
-struct StreamCfg { int kb, kc, nb, ntiles; };
+struct StreamCfg { int kb, nb, ntiles; };
 
 constexpr size_t LDS_MAX = 160 * 1024;
 
@@ -39,27 +39,23 @@ bool stream_cfg(int K, int N, int pro, int epi, StreamCfg& c) {
   if (mode == 0 || K % 32 != 0 || N % 32 != 0) return false;
   const int kb = K / 32, nbt = N / 32;
   const bool fwd = (pro == 0 || pro == 1 || pro == 3) && (epi == 0 || epi == 1 || epi == 5) && !(pro == 3 && epi == 5);
-  const bool bwd = (pro == 2 && (epi == 0 || epi == 2)) || (pro == 2 && epi == 3 && kb == 4 && nbt == 2) ||
-                   (pro == 4 && epi == 2 && kb == 4 && nbt == 4);
+  const bool bwd = (pro == 2 && (epi == 0 || epi == 2)) || (pro == 4 && epi == 2 && kb == 4 && nbt == 4);
   if (!fwd && !bwd) return false;
   if (bwd && mode == 3) return false;                 // mode 3: forward shapes only (A/B of the data-gradient kernels)
-  if (!(kb == 1 || kb == 2 || kb == 4 || kb == 6 || kb == 8 || kb == 12 || kb == 24)) return false;
+  if (!(kb == 1 || kb == 2 || kb == 4)) return false; // K = 32, 64, 128 (wider K: the tiled kernels, see profiles/r02_stream_dgrad_ab.txt)
   if (pro == 3 && kb != 2) return false;
-  if (fwd && kb > 4 && !(pro == 1 && (epi == 1 || epi == 5) && (kb == 6 || kb == 12))) return false;
   // widest column tile (in 32-column blocks) that divides N and whose three W planes + tables fit the LDS
   int nb = 0;
   for (int cand = 4; cand >= 1; cand >>= 1)
     if (nbt % cand == 0 && stream_lds_bytes(K, 32 * cand, pro) <= LDS_MAX) { nb = cand; break; }
   if (nb == 0) return false;
-  if (fwd && kb > 4 && nb != 2) return false;
+  if (pro == 2 && epi == 2 && kb == 2 && nb == 2) return false;   // (this instance does not fit 256 registers without spills: slower)
   const int ntiles = nbt / nb;
   // every column tile streams A again (the tiles of one slab run side by side on the same XCD, so most of it is an L2
   // hit): accept two tiles always, more only when A is the small side of the launch
   if (ntiles > 2 && (int64_t)ntiles * K > 2 * (int64_t)N) return false;
   if (ntiles > 8) return false;
-  // chunk width: what keeps the streamed tensors + accumulators + fragments inside 256 registers (two waves per SIMD)
-  const int kc = (pro == 4) ? 1 : (pro == 2 ? ((kb < 2 || (epi == 2 && nb != 2) || epi == 3) ? 1 : 2) : (kb <= 4 ? kb : 3));
-  c = {kb, kc, nb, ntiles};
+  c = {kb, nb, ntiles};
   // Measured on an MI355X: per shape at M = 32 frames the streaming form runs 1.0-1.45x the tiled kernel (profiles/
   // r02_stream_vs_tiled.txt; only the 64 -> 128 layers with a BatchNorm prologue at multi-million M lose, 0.8-0.9x), and in
   // the whole KD step at 256 frames "every covered shape" beats "only where the micro-benchmark wins" (95.5 vs 96.6 ms
@@ -76,14 +72,19 @@ int stream_grid(int64_t M, int ntiles) {
   return (int)(want < cap ? want : cap);
 }
 
-template <int KB, int KC, int NB>
+template <int KB, int KC, int NB, bool DB>
 int fwd_dispatch(const GemmArgs& g, int pro, int epi, dim3 grid, hipStream_t st) {
-#define KD_SCASE(P_, E_) if (pro == P_ && epi == E_) { stream_launch_one<KB, KC, NB, P_, E_>(g, grid, st); return 1; }
-  if constexpr (KB <= 4) {
-    KD_SCASE(0, 0) KD_SCASE(0, 1) KD_SCASE(1, 0) KD_SCASE(1, 1) KD_SCASE(0, 5) KD_SCASE(1, 5)
-    if constexpr (KB == 2) { KD_SCASE(3, 0) KD_SCASE(3, 1) }
-  } else {
-    KD_SCASE(1, 1) KD_SCASE(1, 5)
+  const bool add = g.addend != nullptr;
+#define KD_SCASE(P_, E_)                                                              \
+  if (pro == P_ && epi == E_) {                                                       \
+    if (add) stream_launch_one<KB, KC, NB, P_, E_, DB, true>(g, grid, st);            \
+    else stream_launch_one<KB, KC, NB, P_, E_, DB, false>(g, grid, st);               \
+    return 1;                                                                         \
+  }
+  if constexpr (!(KB == 2 && !DB)) { KD_SCASE(0, 0) KD_SCASE(0, 1) KD_SCASE(1, 0) KD_SCASE(1, 1) KD_SCASE(0, 5) KD_SCASE(1, 5) }
+  if constexpr (KB == 2 && !DB) {
+    if (!add && pro == 3 && epi == 0) { stream_launch_one<KB, KC, NB, 3, 0, DB, false>(g, grid, st); return 1; }
+    if (!add && pro == 3 && epi == 1) { stream_launch_one<KB, KC, NB, 3, 1, DB, false>(g, grid, st); return 1; }
   }
 #undef KD_SCASE
   return 0;
@@ -105,11 +106,14 @@ int kd_gemm_stream_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {
   if (pro == 2 && epi == 0) rc = kd_stream_bwd0_dispatch(g, c.kb, c.nb, grid, st);
   else if (pro == 2 || pro == 4) rc = kd_stream_bwd2_dispatch(g, c.kb, c.nb, pro, epi, grid, st);
   else {
-#define KD_SHAPE(KB_, KC_, NB_) if (c.kb == KB_ && c.nb == NB_) rc = fwd_dispatch<KB_, KC_, NB_>(g, pro, epi, grid, st);
-    KD_SHAPE(1, 1, 1) KD_SHAPE(1, 1, 2) KD_SHAPE(1, 1, 4)
-    KD_SHAPE(2, 2, 1) KD_SHAPE(2, 2, 2) KD_SHAPE(2, 2, 4)
-    KD_SHAPE(4, 4, 1) KD_SHAPE(4, 4, 2) KD_SHAPE(4, 4, 4)
-    KD_SHAPE(6, 3, 2) KD_SHAPE(12, 3, 2)
+// (K / 32, chunk / 32, N tile / 32, two register sets).  Measured per shape (tools/bench_stream, M = 32 frames): K = 128 and
+    // the BatchNorm-prologue K = 64 layers run 5-15 % faster with 32-column chunks loaded one chunk ahead; the LiDAR layer-1
+    // launch (PRO3: the streamed tensor is the 16-byte point) keeps the single whole-slab load.
+#define KD_SHAPE(KB_, KC_, NB_, DB_) if (c.kb == KB_ && c.nb == NB_) rc = fwd_dispatch<KB_, KC_, NB_, DB_>(g, pro, epi, grid, st);
+    KD_SHAPE(1, 1, 1, false) KD_SHAPE(1, 1, 2, false) KD_SHAPE(1, 1, 4, false)
+    if (pro == 3) { KD_SHAPE(2, 2, 1, false) KD_SHAPE(2, 2, 2, false) KD_SHAPE(2, 2, 4, false) }
+    else { KD_SHAPE(2, 1, 1, true) KD_SHAPE(2, 1, 2, true) KD_SHAPE(2, 1, 4, true) }
+    KD_SHAPE(4, 1, 1, true) KD_SHAPE(4, 1, 2, true) KD_SHAPE(4, 1, 4, true)
 #undef KD_SHAPE
   }
   if (rc == 1) { const int e = kd_check_launch("kd_gemm_stream"); if (e) return -(e > 0 ? e : -e) - 1000; }   // < 0: error

@@ -5,14 +5,16 @@
 using namespace kd_stream;
 
 int kd_stream_bwd0_dispatch(const GemmArgs& g, int kb, int nb, dim3 grid, hipStream_t st) {
-#define KD_B(KB_, KC_, NB_) if (kb == KB_ && nb == NB_) { stream_launch_one<KB_, KC_, NB_, 2, 0>(g, grid, st); return 1; }
-  KD_B(1, 1, 1) KD_B(1, 1, 2) KD_B(1, 1, 4)
-  KD_B(2, 2, 1) KD_B(2, 2, 2) KD_B(2, 2, 4)
-  KD_B(4, 2, 1) KD_B(4, 2, 2) KD_B(4, 2, 4)
-  KD_B(6, 2, 1) KD_B(6, 2, 2) KD_B(6, 2, 4)
-  KD_B(8, 2, 1) KD_B(8, 2, 2)
-  KD_B(12, 2, 1) KD_B(12, 2, 2)
-  KD_B(24, 2, 1)
+  const bool add = g.addend != nullptr;
+#define KD_B(KB_, KC_, NB_, DB_)                                                           \
+  if (kb == KB_ && nb == NB_) {                                                            \
+    if (add) stream_launch_one<KB_, KC_, NB_, 2, 0, DB_, true>(g, grid, st);               \
+    else stream_launch_one<KB_, KC_, NB_, 2, 0, DB_, false>(g, grid, st);                  \
+    return 1;                                                                              \
+  }
+  KD_B(1, 1, 1, false) KD_B(1, 1, 2, false) KD_B(1, 1, 4, false)
+  KD_B(2, 1, 1, true) KD_B(2, 1, 2, true) KD_B(2, 1, 4, true)
+  KD_B(4, 1, 1, true) KD_B(4, 1, 2, true) KD_B(4, 1, 4, true)
 #undef KD_B
   return 0;
 }

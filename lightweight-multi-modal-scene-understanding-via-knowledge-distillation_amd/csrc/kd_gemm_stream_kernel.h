@@ -65,7 +65,9 @@ constexpr int stream_nco(int pro) { return pro == 1 ? 2 : (pro == 3 ? 7 : ((pro 
 constexpr size_t stream_lds_bytes(int K, int N, int pro) { return (size_t)3 * N * K * 2 + (size_t)(stream_nco(pro) > 0 ? stream_nco(pro) : 1) * K * 4; }
 
 // KB = K / 32, KC = chunk width / 32 (divides KB), NB = column-tile width / 32.
-template <int KB, int KC, int NB, int PRO, int EPI>
+// DB: two register sets per streamed tensor -- the loads of chunk c + 1 are issued BEFORE the k-loop of chunk c.
+// ADD: g.addend is added (EPI5: after BatchNorm + activation; otherwise to the raw result, before bias and mask).
+template <int KB, int KC, int NB, int PRO, int EPI, bool DB = false, bool ADD = false>
 __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
   constexpr int K = 32 * KB, N = 32 * NB, CPR = K / 8;
   constexpr int NCH = KB / KC, NUC = 2 * KC;                             // chunks per slab; 16-wide k-steps per chunk
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
   constexpr int WPL = N * K;                                             // bf16 per plane
   constexpr int NCO = stream_nco(PRO);
   constexpr int NT = PRO == 2 ? 2 : (PRO == 4 ? 3 : 1);                  // tensors streamed on the A side
-  constexpr bool EPI_BWD = EPI == 2 || EPI == 3;
+  constexpr bool EPI_BWD = EPI == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* Wh = reinterpret_cast<unsigned short*>(smem_raw);      // [3][N][K] bf16, swizzled
   float* Co = reinterpret_cast<float*>(smem_raw + 3 * WPL * 2);         // [NCO][K] coefficient tables
@@ -114,23 +116,17 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
   // per-lane column constants: column of block j is n0 + 32 j + r (N_total is a multiple of the tile width: no column tail)
   constexpr int NE = (EPI == 5 || EPI_BWD) ? NB : 1;
   float bias[NB], esc[NE], esh[NE], emean[EPI_BWD ? NB : 1], einv[EPI_BWD ? NB : 1];
-  float4 ew[EPI == 3 ? NB : 1];
-  float eb[EPI == 3 ? NB : 1];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int c = n0 + 32 * j + r;
     bias[j] = g.bias ? g.bias[c] : 0.f;
     if (EPI == 5 || EPI_BWD) { esc[j] = g.esc[c]; esh[j] = g.esh[c]; }
     if (EPI_BWD) { emean[j] = g.emean[c]; einv[j] = g.einv[c]; }
-    if constexpr (EPI == 3) { ew[j] = kd_ld4(g.l0w + c * 4); eb[j] = g.l0b[c]; }
   }
   constexpr int NS = (EPI == 1 || EPI_BWD) ? NB : 1;
   float s1[NS], s2[NS];
 #pragma unroll
   for (int j = 0; j < NS; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-  float4 m1[EPI == 3 ? NB : 1];                                          // EPI3: sum over rows of G0 * point, per column
-#pragma unroll
-  for (int j = 0; j < (EPI == 3 ? NB : 1); ++j) m1[j] = kd_zero4();
 
   constexpr int NA = PRO == 3 ? 1 : 2 * NUC;                             // float4 registers per streamed tensor per chunk
   // (plain cache policy on purpose: a lane reads 32 bytes of a 128-byte line per k-step, four instructions touch each line --
@@ -272,48 +268,16 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
     constexpr bool FULL = decltype(full_tag)::value;              // every row of the slab is < M: no predicates at all
     constexpr int QG = NB >= 4 ? 8 : 16;         // (the split that keeps hipcc inside the register budget without spills)
     const int64_t m0 = s * 32;
-    const float* addend = g.addend;
-    if constexpr (EPI == 3) {
-      // X = layer 0 of the row's point, recomputed: four rows' points at a time (16-byte loads, one address per half wave)
-#pragma unroll
-      for (int qg = 0; qg < 4; ++qg) {
-        float4 pt[4];
-#pragma unroll
-        for (int qi = 0; qi < 4; ++qi) {
-          int64_t row = m0 + qi + 8 * qg + 4 * h;
-          row = row < M ? row : M - 1;
-          pt[qi] = kd_ld4(g.X + row * 4);
-        }
-#pragma unroll
-        for (int qi = 0; qi < 4; ++qi) {
-          const int q = 4 * qg + qi, rbase = qi + 8 * qg;
-          const bool rok = FULL || (m0 + rbase + 4 * h < M);
-#pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            const float x = kd_l0_raw(pt[qi], ew[j], eb[j]);
-            float v = acc[j][q] + bias[j];
-            v *= kd_act_mask(kd_affine(x, esc[j], esh[j]), g.epi_act);
-            if (rok) {
-              s1[j] += v;
-              s2[j] = fmaf(v, (x - emean[j]) * einv[j], s2[j]);
-              m1[j].x = fmaf(v, pt[qi].x, m1[j].x); m1[j].y = fmaf(v, pt[qi].y, m1[j].y);
-              m1[j].z = fmaf(v, pt[qi].z, m1[j].z); m1[j].w = fmaf(v, pt[qi].w, m1[j].w);
-              if (g.C) g.C[(m0 + rbase) * g.ldc + n0 + 32 * j + c_lane] = v;
-            }
-          }
-        }
-      }
-      return;
-    }
+    const float* addend = ADD ? g.addend : nullptr;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       float* cbase = g.C + m0 * g.ldc + n0 + 32 * j;               // wave-uniform
-      const float* abase = addend ? addend + m0 * g.ldadd + n0 + 32 * j : nullptr;
+      const float* abase = ADD ? addend + m0 * g.ldadd + n0 + 32 * j : nullptr;
       const float* xbase = EPI == 2 ? g.X + m0 * g.ldx + n0 + 32 * j : nullptr;
 #pragma unroll
       for (int hq = 0; hq < 16 / QG; ++hq) {                       // QG registers at a time: their side loads first, then the stores
-        float ad[QG], xr[EPI == 2 ? QG : 1];
-        if (addend) {                                             // residual values, in the layout of the stores below
+        float ad[ADD ? QG : 1], xr[EPI == 2 ? QG : 1];
+        if constexpr (ADD) {                                             // residual values, in the layout of the stores below
 #pragma unroll
           for (int qi = 0; qi < QG; ++qi) {
             const int q = QG * hq + qi, rbase = (q & 3) + 8 * (q >> 2);
@@ -334,12 +298,12 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
           const int q = QG * hq + qi, rbase = (q & 3) + 8 * (q >> 2);   // row of register q within the slab, before + 4 h
           const bool rok = FULL || (m0 + rbase + 4 * h < M);
           float v = acc[j][q];
-          if (EPI != 5 && addend) v += ad[qi];                     // gradient of the residual branch: before the bias and the mask
+          if constexpr (EPI != 5 && ADD) v += ad[qi];                     // gradient of the residual branch: before the bias and the mask
           v += bias[j];
           if (EPI == 1 && rok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
           if (EPI == 5) {
             v = kd_act(kd_affine(v, esc[j], esh[j]), g.epi_act);
-            if (addend) v += ad[qi];
+            if constexpr (ADD) v += ad[qi];
           }
           if constexpr (EPI == 2) {
             const float x = xr[qi];
@@ -361,12 +325,13 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
   // chunk of the slab, or chunk 0 of the wave's next slab) are issued into it right after the k-loop and fly during the
   // epilogue; what latency is left is covered by the second wave of the SIMD (two waves per SIMD run the same program
   // out of phase).  All waits are hipcc's own (in-order vmcnt: loads, then the stores). ---------------------------------
-  f4v rc[NT][NA];
+  static_assert(!DB || (NCH >= 2 && NCH % 2 == 0), "double buffering alternates two register sets over an even number of chunks");
+  f4v rc[DB ? 2 : 1][NT][NA];
   Frag a_cur, b_cur;
   int64_t s = wid;
   if (s < nslab) {
     if constexpr (PRO == 4) trow_nxt = fetch_trow(s);
-    load_unit(s, 0, rc);
+    load_unit(s, 0, rc[0]);
     load_b(Wh, 0, 0, b_cur);
   }
 #ifdef KD_STREAM_DBG
@@ -389,12 +354,18 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
     const float* Cq = Co + pin0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      conv_all(rc, Cq, c * NUC, a_cur);
+      if constexpr (DB) {                            // next unit first: it flies during this chunk's whole k-loop
+        if (c < NCH - 1) load_unit(s, c + 1, rc[(c + 1) & 1]);
+        else if (more) load_unit(s + wtot, 0, rc[0]);
+      }
+      conv_all(rc[DB ? (c & 1) : 0], Cq, c * NUC, a_cur);
       KD_SSTAMP(0);
-      compute_chunk(rc, c, a_cur, b_cur, acc);
+      compute_chunk(rc[DB ? (c & 1) : 0], c, a_cur, b_cur, acc);
       KD_SSTAMP(1);
-      if (c < NCH - 1) load_unit(s, c + 1, rc);
-      else if (more) load_unit(s + wtot, 0, rc);
+      if constexpr (!DB) {
+        if (c < NCH - 1) load_unit(s, c + 1, rc[0]);
+        else if (more) load_unit(s + wtot, 0, rc[0]);
+      }
     }
     if (s * 32 + 32 <= M) store_slab(s, acc, std::true_type{}); else store_slab(s, acc, std::false_type{});
     KD_SSTAMP(2);
@@ -420,30 +391,17 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
       }
     }
   }
-  if constexpr (EPI == 3) {
-    if (g.m1slab) {                  // the four G0 * point moments, one slab row per wave: [wid][4][N_total]
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const float t[4] = {m1[j].x + __shfl_xor(m1[j].x, 32, 64), m1[j].y + __shfl_xor(m1[j].y, 32, 64),
-                            m1[j].z + __shfl_xor(m1[j].z, 32, 64), m1[j].w + __shfl_xor(m1[j].w, 32, 64)};
-        if (h == 0) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) g.m1slab[(wid * 4 + i) * g.N + n0 + 32 * j + r] = t[i];
-        }
-      }
-    }
-  }
 }
 
-template <int KB, int KC, int NB, int PRO, int EPI>
+template <int KB, int KC, int NB, int PRO, int EPI, bool DB = false, bool ADD = false>
 inline void stream_launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
   constexpr size_t lds = stream_lds_bytes(32 * KB, 32 * NB, PRO);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)pw_stream_kernel<KB, KC, NB, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)pw_stream_kernel<KB, KC, NB, PRO, EPI, DB, ADD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((pw_stream_kernel<KB, KC, NB, PRO, EPI>), grid, dim3(64 * SW), lds, st, g);
+  hipLaunchKernelGGL((pw_stream_kernel<KB, KC, NB, PRO, EPI, DB, ADD>), grid, dim3(64 * SW), lds, st, g);
 }
 
 }  // namespace kd_stream
