@@ -709,6 +709,132 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(DwBwdArgs a) {
   if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
 }
 
+// stride-2 data AND weight gradient in one pass over the same quads: the pairs (dy, input pixel) of the weight gradient
+//   dw[kh][kw] = sum dy(ho, wo) x(2 ho - 1 + kh, 2 wo - 1 + kw)
+// that involve the quad's four pixels are exactly the nine products of the data-gradient formulas above (pixel (0,0): d00 ->
+// tap 11; (0,1): d01 -> 10, d00 -> 12; (1,0): d10 -> 01, d00 -> 21; (1,1): d11 -> 00, d10 -> 02, d01 -> 20, d00 -> 22), every
+// input pixel belongs to one quad, so each pair is counted once.  The separate kernels read dy, Y and the raw input twice.
+__global__ __launch_bounds__(256) void dw_bwd_fused_s2_kernel(DwBwdArgs a) {
+  __shared__ float red[2 * 256 * 4];
+  float4 wacc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wacc[t] = kd_zero4();
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  const bool active = slot < a.slots;
+  const int c0 = gidx * 4;
+  float4 s1 = kd_zero4(), s2 = kd_zero4();
+  if (active) {
+    float4 wt[9];                         // wt[t] = tap t of the thread's 4 channels
+    {
+      float wreg[4][9];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wreg[j][t] = a.w[(c0 + j) * 9 + t];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wt[t] = make_float4(wreg[0][t], wreg[1][t], wreg[2][t], wreg[3][t]);
+    }
+    float4 al = kd_zero4(), be = kd_zero4(), ga = kd_zero4(), dsc = kd_zero4(), dsh = kd_zero4();
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4(), mean = kd_zero4(), inv = kd_zero4();
+    if (a.al) { al = kd_ld4(a.al + c0); be = kd_ld4(a.be + c0); ga = kd_ld4(a.ga + c0); }
+    if (a.dsc) { dsc = kd_ld4(a.dsc + c0); dsh = kd_ld4(a.dsh + c0); }
+    if (a.sc) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
+    if (a.mean) { mean = kd_ld4(a.mean + c0); inv = kd_ld4(a.invstd + c0); }
+    const bool masked = a.sc != nullptr;
+    const int QH = (a.H + 1) / 2, QW = (a.W + 1) / 2;
+    constexpr int QSEG = DW_SEG / 2;
+    const int nseg = (QH + QSEG - 1) / QSEG;
+    const int64_t items = (int64_t)a.B * nseg * QW;
+    // raw x of the quad's four pixels (clamped addresses; pixels outside an odd-sized image are dropped at the store)
+    auto load_x = [&](int b, int qa, int q, float4 (&xq)[4]) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int hi = 2 * qa + (k >> 1), wi = 2 * q + (k & 1);
+        hi = hi < a.H ? hi : a.H - 1; wi = wi < a.W ? wi : a.W - 1;
+        xq[k] = kd_ld4(a.x + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0);
+      }
+    };
+    for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+      const int q = (int)(it % QW), sg = (int)((it / QW) % nseg), b = (int)(it / ((int64_t)QW * nseg));
+      const int a0 = sg * QSEG, a1 = a0 + QSEG < QH ? a0 + QSEG : QH;
+      const bool w0ok = q < a.Wo, w1ok = q + 1 < a.Wo;
+      float4 d00 = dw_dy_finish(a, dw_dy_raw(a, b, a0, q, c0), a0 < a.Ho && w0ok, al, be, ga, dsc, dsh);
+      float4 d01 = dw_dy_finish(a, dw_dy_raw(a, b, a0, q + 1, c0), a0 < a.Ho && w1ok, al, be, ga, dsc, dsh);
+      // Everything a quad row needs is loaded one iteration AHEAD, i.e. before the previous row's stores are issued:
+      // vmcnt retires in order, so a wait on a load that follows a store would also wait for that store.
+      DwRaw rn0 = dw_dy_raw(a, b, a0 + 1, q, c0), rn1 = dw_dy_raw(a, b, a0 + 1, q + 1, c0);
+      float4 xn[4];
+      load_x(b, a0, q, xn);
+      for (int qa = a0; qa < a1; ++qa) {
+        const bool hok = qa + 1 < a.Ho;
+        const float4 d10 = dw_dy_finish(a, rn0, hok && w0ok, al, be, ga, dsc, dsh), d11 = dw_dy_finish(a, rn1, hok && w1ok, al, be, ga, dsc, dsh);
+        float4 xc[4] = {xn[0], xn[1], xn[2], xn[3]};
+        rn0 = dw_dy_raw(a, b, qa + 2, q, c0); rn1 = dw_dy_raw(a, b, qa + 2, q + 1, c0);
+        load_x(b, qa + 1 < QH ? qa + 1 : qa, q, xn);
+        float4 g[4];
+        g[0].x = d00.x * wt[4].x; g[0].y = d00.y * wt[4].y; g[0].z = d00.z * wt[4].z; g[0].w = d00.w * wt[4].w;
+        g[1].x = fmaf(d01.x, wt[3].x, d00.x * wt[5].x); g[1].y = fmaf(d01.y, wt[3].y, d00.y * wt[5].y);
+        g[1].z = fmaf(d01.z, wt[3].z, d00.z * wt[5].z); g[1].w = fmaf(d01.w, wt[3].w, d00.w * wt[5].w);
+        g[2].x = fmaf(d10.x, wt[1].x, d00.x * wt[7].x); g[2].y = fmaf(d10.y, wt[1].y, d00.y * wt[7].y);
+        g[2].z = fmaf(d10.z, wt[1].z, d00.z * wt[7].z); g[2].w = fmaf(d10.w, wt[1].w, d00.w * wt[7].w);
+        g[3].x = fmaf(d11.x, wt[0].x, fmaf(d10.x, wt[2].x, fmaf(d01.x, wt[6].x, d00.x * wt[8].x)));
+        g[3].y = fmaf(d11.y, wt[0].y, fmaf(d10.y, wt[2].y, fmaf(d01.y, wt[6].y, d00.y * wt[8].y)));
+        g[3].z = fmaf(d11.z, wt[0].z, fmaf(d10.z, wt[2].z, fmaf(d01.z, wt[6].z, d00.z * wt[8].z)));
+        g[3].w = fmaf(d11.w, wt[0].w, fmaf(d10.w, wt[2].w, fmaf(d01.w, wt[6].w, d00.w * wt[8].w)));
+        {   // weight gradient: the activated input of the quad (zero outside an odd-sized image)
+          float4 xa[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool ok = 2 * qa + (k >> 1) < a.H && 2 * q + (k & 1) < a.W;
+            const float4 t = masked ? kd_affine_act4(xc[k], sc, sh, a.act) : xc[k];
+            xa[k] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+          }
+#define KD_WG(T, D, X) wacc[T].x = fmaf(D.x, X.x, wacc[T].x); wacc[T].y = fmaf(D.y, X.y, wacc[T].y); wacc[T].z = fmaf(D.z, X.z, wacc[T].z); wacc[T].w = fmaf(D.w, X.w, wacc[T].w);
+          KD_WG(4, d00, xa[0])
+          KD_WG(3, d01, xa[1]) KD_WG(5, d00, xa[1])
+          KD_WG(1, d10, xa[2]) KD_WG(7, d00, xa[2])
+          KD_WG(0, d11, xa[3]) KD_WG(2, d10, xa[3]) KD_WG(6, d01, xa[3]) KD_WG(8, d00, xa[3])
+#undef KD_WG
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int hi = 2 * qa + (k >> 1), wi = 2 * q + (k & 1);
+          const bool ok = hi < a.H && wi < a.W;
+          float4 v = g[k];
+          if (masked) {
+            const float4 xr = xc[k];
+            v.x *= kd_act_mask(kd_affine(xr.x, sc.x, sh.x), a.act);
+            v.y *= kd_act_mask(kd_affine(xr.y, sc.y, sh.y), a.act);
+            v.z *= kd_act_mask(kd_affine(xr.z, sc.z, sh.z), a.act);
+            v.w *= kd_act_mask(kd_affine(xr.w, sc.w, sh.w), a.act);
+            if (ok) {
+              s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+              s2.x = fmaf(v.x, (xr.x - mean.x) * inv.x, s2.x);
+              s2.y = fmaf(v.y, (xr.y - mean.y) * inv.y, s2.y);
+              s2.z = fmaf(v.z, (xr.z - mean.z) * inv.z, s2.z);
+              s2.w = fmaf(v.w, (xr.w - mean.w) * inv.w, s2.w);
+            }
+          }
+          if (ok) { if (a.nt) kd_st4_nt(a.gx + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0, v); else kd_st4(a.gx + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0, v); }
+        }
+        d00 = d10; d01 = d11;
+      }
+    }
+  }
+  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
+  for (int t = 0; t < 9; ++t) {        // per-block weight-gradient partials, summed in fixed order by kd_slab_reduce
+    __syncthreads();
+    kd_st4(red + tid * 4, active ? wacc[t] : kd_zero4());
+    __syncthreads();
+    for (int c = tid; c < a.C; c += 256) {
+      float s = 0.f;
+      for (int sl = 0; sl < a.slots; ++sl) s += red[(sl * a.groups + c / 4) * 4 + (c & 3)];
+      a.wslab[(int64_t)blockIdx.x * a.C * 9 + c * 9 + t] = s;
+    }
+  }
+}
+
 // weight gradient with the same input window as the forward
 template <int STRIDE>
 __global__ __launch_bounds__(256) void dw_bwd_weight_sw_kernel(DwBwdArgs a) {
@@ -836,8 +962,9 @@ int kd_dwconv3x3_fwd(const float* x, const float* sc, const float* sh, int act, 
   return kd_check_launch("kd_dwconv3x3_fwd");
 }
 
+// (one slab row per workgroup; the fused stride-2 kernel is launched over the INPUT pixels: at most 4 per output pixel)
 size_t kd_dwconv_bwd_ws_bytes(int64_t npix_out, int C) {
-  return (size_t)kd_cg_layout(npix_out, C).grid * (size_t)C * 9 * sizeof(float);
+  return (size_t)kd_cg_layout(4 * npix_out, C).grid * (size_t)C * 9 * sizeof(float);
 }
 
 // Backward of y = dwconv3x3(act(x*sc+sh)).  (D, Y, al, be, ga[, dsc, dsh, d_act]) describe dL/dy_raw;
@@ -865,6 +992,16 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
     } else
     hipLaunchKernelGGL(dw_bwd_fused_s1_kernel, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(fused)");
+    if (rc) return rc;
+    return kd_slab_reduce_launch((const float*)ws, l.grid, (int64_t)C * 9, dw, st);
+  }
+  if (gx && dw && stride == 2 && dw_mode != 0) {               // stride 2: the same fusion over 2x2 input quads
+    const KdCgLayout l = kd_cg_layout((int64_t)B * H * W, C);
+    KD_REQUIRE(ws && ws_bytes >= (size_t)l.grid * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
+    DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,
+                (float*)ws, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
+    hipLaunchKernelGGL(dw_bwd_fused_s2_kernel, dim3(l.grid), dim3(256), 0, st, a);
+    int rc = kd_check_launch("kd_dwconv3x3_bwd(fused, stride 2)");
     if (rc) return rc;
     return kd_slab_reduce_launch((const float*)ws, l.grid, (int64_t)C * 9, dw, st);
   }

@@ -352,6 +352,46 @@ def test_dw_stride1_backward_forms_agree(shape):
         assert ((wv - w0).abs().max() / w0.abs().max()).item() < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 13, 19, 8), (1, 70, 66, 72), (2, 32, 64, 192), (1, 9, 9, 384)])
+@pytest.mark.parametrize("deferred", (True, False))
+def test_dw_stride2_backward_forms_agree(shape, deferred):
+    """Stride-2 depthwise backward: separate data / weight kernels against the fused quad walk, on odd and even sizes,
+    with a deferred (BatchNorm + ReLU6 on load) and a materialised input: same data gradient bits, weight gradient and
+    BatchNorm-backward sums to rounding."""
+    from kdrt.lib import lib
+    from kdrt.ops import P, stream, workspace
+    B, H, W, C = shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g = torch.Generator(device="cuda").manual_seed(9)
+    rnd = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    D, Y, x, w = rnd(B * Ho * Wo, C), rnd(B * Ho * Wo, C), rnd(B * H * W, C), rnd(C, 9)
+    al, be, ga, sc, sh, mean = rnd(C), rnd(C) * 0.1, rnd(C) * 0.1, rnd(C).abs() + 0.5, rnd(C) * 0.2, rnd(C) * 0.1
+    inv = rnd(C).abs() + 0.5
+    outs = []
+    prev = lib.kd_set_dw_bwd_mode(0)
+    try:
+        for mode in (0, 3):
+            lib.kd_set_dw_bwd_mode(mode)
+            rows = lib.kd_dwconv_bwd_stat_rows(B * H * W, C)
+            gx = torch.full((B * H * W, C), float("nan"), device="cuda")
+            part = torch.full((rows * 2 * C,), float("nan"), device="cuda") if deferred else None
+            dw = torch.full((C, 9), float("nan"), device="cuda")
+            nbytes = lib.kd_dwconv_bwd_ws_bytes(B * Ho * Wo, C)
+            ws = workspace(nbytes, gx.device)
+            lib.call("kd_dwconv3x3_bwd", P(D), P(Y), P(al), P(be), P(ga), None, None, 0, P(x), P(sc) if deferred else None,
+                     P(sh) if deferred else None, 2, P(mean) if deferred else None, P(inv) if deferred else None, P(w), P(gx), P(part), P(dw),
+                     B, H, W, C, 2, P(ws), nbytes, stream())
+            torch.cuda.synchronize()
+            outs.append((gx, part.view(rows, 2, C).double().sum(0) if deferred else None, dw))
+    finally:
+        lib.kd_set_dw_bwd_mode(prev)
+    (g0, p0, w0), (g1, p1, w1) = outs
+    assert torch.equal(g0, g1)
+    if deferred:
+        assert ((p1 - p0).abs().max() / p0.abs().max()).item() < 1e-5
+    assert ((w1 - w0).abs().max() / w0.abs().max()).item() < 2e-5
+
+
 def test_fpn_sum_single_pass_equals_accumulate():
     """kd_bilinear_sum_fwd (the FPN sum of fusion_module.py:58-63 in one pass) against lateral-by-lateral
     kd_bilinear_accum_fwd: the same bits, for 1..3 laterals with mixed geometry and activations."""
