@@ -56,10 +56,9 @@ bool stream_cfg(int K, int N, int pro, int epi, StreamCfg& c) {
   if (ntiles > 2 && (int64_t)ntiles * K > 2 * (int64_t)N) return false;
   if (ntiles > 8) return false;
   c = {kb, nb, ntiles};
-  // Measured on an MI355X: per shape at M = 32 frames the streaming form runs 1.0-1.45x the tiled kernel (profiles/
-  // r02_stream_vs_tiled.txt; only the 64 -> 128 layers with a BatchNorm prologue at multi-million M lose, 0.8-0.9x), and in
-  // the whole KD step at 256 frames "every covered shape" beats "only where the micro-benchmark wins" (95.5 vs 96.6 ms
-  // per step; 97.1 ms with the tiled kernels alone) -- so every covered shape is the default; mode 1 keeps the narrow rule.
+  // Measured on an MI355X (profiles/r02_stream_vs_tiled.txt, r02_stream_dgrad_ab.txt): the forward shapes run 1.0-1.45x the
+  // tiled kernel, the K <= 128 data gradients 1.0-1.2x (LiDAR layer 2: 8.2 -> 7.3 ms); K >= 192 loses in every form tried
+  // and stays tiled.  "Every covered shape" is the default; mode 1 keeps the narrow forward-only rule of the first version.
   if (mode >= 2) return true;
   return fwd && ntiles == 1 && kb <= 4 && (nb <= 2 || (kb == 4 && nb == 4) || (pro == 3 && epi == 1));
 }

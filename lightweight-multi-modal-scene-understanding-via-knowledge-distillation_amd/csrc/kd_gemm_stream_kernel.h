@@ -1,6 +1,6 @@
 // kd_gemm_stream_kernel.h -- the weight-resident STREAMING 1x1-convolution GEMM kernel (split bf16x3 arithmetic, gfx950).
-// Included by the translation units that instantiate it (kd_gemm_stream.hip: forward shapes, kd_gemm_stream_bwd.hip: the
-// data-gradient shapes); the dispatch logic lives in kd_gemm_stream.hip.
+// Included by the translation units that instantiate it (kd_gemm_stream.hip: forward shapes, kd_gemm_stream_bwd0.hip /
+// kd_gemm_stream_bwd2.hip: the data-gradient shapes); the dispatch logic lives in kd_gemm_stream.hip.
 //
 // The dense layers of this network are skinny: M = B*H*W or B*N_points rows in the millions, K and N in 32..768
 // (reference: camera_encoder.py:24,39, fusion_module.py:12,29,116, lidar_encoder.py:29,32).  A 128x128-tile kernel
@@ -16,11 +16,15 @@
 //     A[row r][k = 16u + 8h .. +7]: two float4 of row r), applies the operand transform -- deferred BatchNorm +
 //     activation (PRO1), LiDAR layer 0 recomputed from the 16-byte point (PRO3), the BatchNorm-backward operand
 //     al*(D*mask) + be*X + ga from TWO streamed tensors (PRO2), the same with the scatter-max gradient rebuilt from the
-//     per-cell tables (PRO4) -- and cuts the eight values into three bf16x8 fragments in registers.  That VALU work sits
+//     per-cell tables (PRO4: three streamed tensors) -- and cuts the eight values into three bf16x8 fragments in registers.  That VALU work sits
 //     in the shadow of the MFMAs of the previous k-step;
-//   * a slab is walked in K-CHUNKS of 32*KC columns: one chunk of every streamed tensor is in registers at a time
-//     (two-tensor prologues and K up to 768 fit the 256-register budget of two waves per SIMD), the next chunk's loads
-//     are issued as soon as the chunk's MFMAs are, and fly during the epilogue when the chunk was the slab's last;
+//   * a slab is walked in K-CHUNKS of 32*KC columns, one chunk of every streamed tensor per register set.  With two
+//     register sets (DB) the loads of chunk c + 1 are issued BEFORE the k-loop of chunk c and have its 1 500-3 000
+//     matrix-pipe cycles to land (the loaded HBM latency is ~4 000 cycles; the rest is covered by the partner wave);
+//     with one set the next unit's loads are issued after the k-loop and fly during the epilogue only.  Two sets of 32
+//     columns cost the registers of one set of 64: that is what lets the two-tensor data-gradient prologue fit the
+//     256-register budget of two waves per SIMD, and it runs the K = 128 forward layers 5-15 % faster than one
+//     whole-slab load (profiles/r02_stream_vs_tiled.txt);
 //   * the accumulator tile goes to HBM directly: register q of a 32x32 block is one 128-byte row segment per half
 //     wave (full-rate dword stores); the data-gradient epilogue (EPI2) reads the raw tensor whose activation is
 //     differentiated in the same layout.  BatchNorm statistics are per-lane column sums kept in registers ACROSS the slabs

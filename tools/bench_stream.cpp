@@ -104,6 +104,40 @@ int main(int argc, char** argv) {
              rows0, rows1, ndiff, md, sd, ok ? "OK" : "MISMATCH");
     }
   }
+  // ---- data gradient: dX = (al*(G*mask) + be*Y + ga) . W^T [* act'(X), BatchNorm-backward sums] -- the K <= 128 reductions --------
+  struct DShape { const char* name; long M; int K, N; };     // K = reduction width (the layer's output channels), N = its input channels
+  std::vector<DShape> dshapes = {{"stage1 project 32<-32", scale * 16384, 32, 32}, {"stage3 project 384<-64", scale * 4096, 64, 384},
+                                 {"stage5 project 768<-128", scale * 1024, 128, 768}, {"fpn/fusion 128<-128", scale * 4096, 128, 128},
+                                 {"head 128<-64", scale * 4096, 64, 128}, {"odd M 128<-128", 100003, 128, 128}};
+  float *al = vec + 8192, *be = vec + 9216, *ga = vec + 10240, *mean = vec + 11264, *inv = vec + 12288;
+  for (auto& s : dshapes) {
+    const double fl = 2.0 * s.M * s.K * s.N;
+    for (int epi = 0; epi <= 2; epi += 2) {
+      const double by = 4.0 * ((double)s.M * s.K * 2 + (double)s.M * s.N * (epi == 2 ? 2 : 1));
+      auto run = [&](float* out, float* part) {
+        RC(kd_pwconv_gemm(A, s.K, add, s.K, 2, 2, al, be, ga, sc, sh, W, nullptr, out, s.N, nullptr, 0, epi, epi == 2 ? add : nullptr, s.N, esc, esh,
+                          mean, inv, 2, part, s.M, s.K, s.N, nullptr, nullptr));
+      };
+      kd_set_gemm_stream(0);
+      const long rows0 = kd_pwconv_stat_rows_for(s.M, s.K, s.N, 2, epi);
+      CK(hipMemset(C2, 0xff, (size_t)s.M * s.N * 4));
+      float t_old = timeit([&] { run(C2, partial2); });
+      kd_set_gemm_stream(2);
+      const long rows1 = kd_pwconv_stat_rows_for(s.M, s.K, s.N, 2, epi);
+      CK(hipMemset(C, 0xee, (size_t)s.M * s.N * 4));
+      float t_new = timeit([&] { run(C, partial); });
+      const size_t n = (size_t)s.M * s.N;
+      std::vector<float> r0(std::min(n, (size_t)1 << 24)), r1(r0.size());
+      const size_t off = n > r0.size() ? n - r0.size() : 0;
+      CK(hipMemcpy(r0.data(), C2 + off, r0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), C + off, r1.size() * 4, hipMemcpyDeviceToHost));
+      size_t ndiff = 0;
+      for (size_t i = 0; i < r0.size(); ++i) ndiff += !(r0[i] == r1[i]);
+      bad += ndiff != 0;
+      printf("dgrad %-24s M=%9ld epi%d | tiled %8.1fus %6.1fTF %5.2fTB/s | stream %8.1fus %6.1fTF %5.2fTB/s | x%.2f | rows %ld -> %ld | diff %zu %s\n",
+             s.name, s.M, epi, t_old * 1e3, fl / t_old / 1e9, by / t_old / 1e9, t_new * 1e3, fl / t_new / 1e9, by / t_new / 1e9, t_old / t_new,
+             rows0, rows1, ndiff, ndiff ? "MISMATCH" : (rows0 == rows1 && epi == 2 ? "(tiled in both modes)" : "OK"));
+    }
+  }
   printf(bad ? "FAILED: %d mismatching cases\n" : "all cases bit-identical\n", bad);
   return bad != 0;
 }
