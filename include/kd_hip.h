@@ -292,6 +292,19 @@ int kd_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float
 int kd_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, float beta1,
                       float beta2, float eps, float weight_decay, float ginv, void* stream);
 
+/* ---- inference-mode block fusion (csrc/kd_block.hip) ------------------------------------------------------------------
+ * The tail of an InvertedResidual (reference camera_encoder.py:30-42: depthwise 3x3 + BN + ReLU6, project 1x1 + BN, + x) or a
+ * whole DWSeparableConv (fusion_module.py:25-34) in ONE kernel for the eval-mode / no-grad forward: every BatchNorm is an
+ * (scale, shift) pair known before the launch, so the depthwise output -- the widest tensor of the block -- never goes to HBM.
+ *   out[B*Ho*Wo, Cout] = pact(bn_p(conv1x1(dact(bn_d(dwconv3x3_stride(iact(bn_i(x)))))))) (+ res)
+ * x: [B,H,W,Ch] NHWC (isc == NULL: used as it is), wd: [Ch][9], wp: [Cout][Ch]; split bf16x3 GEMM arithmetic; bit-identical to
+ * kd_dwconv3x3_fwd followed by kd_pwconv_gemm(pro 1, epi 5).  Shapes: Ch a multiple of 32; stride 1 with Cout 32 / 64 / 128,
+ * stride 2 with Cout 64 / 128 (kd_dw_pw_infer_supported); anything else returns KD_ERR_SHAPE. */
+int kd_dw_pw_infer_supported(int Ch, int Cout, int stride);
+int kd_dw_pw_infer(const float* x, const float* isc, const float* ish, int iact, const float* wd, const float* dsc, const float* dsh,
+                   int dact, const float* wp, const float* pbias, const float* psc, const float* psh, int pact, const float* res,
+                   int64_t ldres, float* out, int64_t ldo, int B, int H, int W, int Ch, int stride, int Cout, void* stream);
+
 /* ---- bf16-storage INFERENCE path (csrc/kd_bf16.hip; BASELINE.json configs[1]) -----------------------------------------
  * A second mode beside the fp32 contract: eval forward only.  Activations are bf16 NHWC matrices [M][C], already
  * normalised + activated; every entry point is one whole unit conv -> fma(raw, sc, sh) -> act (+ residual) -> bf16, with

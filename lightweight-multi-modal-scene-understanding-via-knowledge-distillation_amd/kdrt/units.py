@@ -199,6 +199,64 @@ def pw_forward_final(spec: UnitSpec, inp: Operand, res: Optional[torch.Tensor] =
     return y
 
 
+# Inference tails that end in (depthwise 3x3, 1x1): one kernel for both units (csrc/kd_block.hip) -- the depthwise output, the
+# widest tensor of an InvertedResidual / DWSeparableConv, is never written.  Measured inside the KD step at 256 frames
+# (profiles/r02_dw_pw_fusion.txt): the one-kernel form wins where the hidden tensor is wide and the output narrow (stage 2:
+# 192 -> 64 at stride 2, 1065 -> 916 us; stage 3: 384 -> 64, 1211 -> 1085 us) and loses elsewhere (its 128-pixel tiles expose one
+# HBM latency per 32-channel chunk), so mode 1 (default) uses it for those shapes only.  KD_DW_PW_FUSED: 0 never, 1 by shape, 2 always.
+DW_PW_FUSED = [int(os.environ.get("KD_DW_PW_FUSED", "1"))]
+
+
+def dw_pw_tail_ok(units, cur: Operand) -> bool:
+    mode = DW_PW_FUSED[0]
+    if mode == 0 or len(units) < 2 or units[-2].kind != "dw" or units[-1].kind != "pw":
+        return False
+    if ops.get_gemm_arithmetic() != "split" or not isinstance(cur, Operand):
+        return False
+    if ld(cur.raw) != cur.C:                                      # the depthwise input must be a dense NHWC matrix
+        return False
+    dwu, pwu = units[-2], units[-1]
+    Ch, Cout = dwu.conv.weight.shape[0], pwu.conv.weight.shape[0]
+    if not lib.kd_dw_pw_infer_supported(Ch, Cout, dwu.stride):
+        return False
+    return mode >= 2 or (Cout == 64 and Ch >= 192)
+
+
+def dw_pw_forward_final(dwu: UnitSpec, pwu: UnitSpec, inp: Operand, res: Optional[torch.Tensor] = None):
+    """(depthwise 3x3 + BN + act) -> (1x1 + BN + act) [+ residual] of an inference tail in one launch -> (matrix, geom);
+    the same bits as unit_forward(dw) followed by pw_forward_final (tests/test_gpu_units.py)."""
+    B, H, W = inp.geom
+    Ch, Cout = inp.C, pwu.conv.weight.shape[0]
+    if dwu.conv.weight.shape[0] != Ch or pwu.conv.weight.shape[1] != Ch:
+        raise KDError(f"depthwise / pointwise pair expects {dwu.conv.weight.shape[0]} channels, got {Ch}")
+    s = dwu.stride
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    dev = inp.raw.device
+    bd = _coeffs(dwu, None, 0, Ch, B * Ho * Wo, False, None, dev)
+    bp = _coeffs(pwu, None, 0, Cout, B * Ho * Wo, False, None, dev)
+    out = torch.empty(B * Ho * Wo, Cout, device=dev, dtype=torch.float32)
+    lib.call("kd_dw_pw_infer", P(inp.raw), P(inp.sc), P(inp.sh), inp.act, P(dwu.conv.weight), P(bd.scale), P(bd.shift), dwu.act,
+             P(pwu.conv.weight), P(pwu.conv.bias), P(bp.scale), P(bp.shift), pwu.act, P(res), ld(res) if res is not None else 0,
+             P(out), Cout, B, H, W, Ch, s, Cout, stream())
+    return out, (B, Ho, Wo)
+
+
+def infer_tail(units, cur, res: Optional[torch.Tensor] = None):
+    """The units of an inference-mode chain whose last unit is a 1x1 conv -> (finished output matrix, geometry)."""
+    n_head = len(units) - 2
+    if n_head >= 0:
+        head = cur
+        for u in units[:n_head]:
+            head, _ = unit_forward(u, head, False)
+        if dw_pw_tail_ok(units, head):
+            return dw_pw_forward_final(units[-2], units[-1], head, res)
+        cur = head
+        units = units[n_head:]
+    for u in units[:-1]:
+        cur, _ = unit_forward(u, cur, False)
+    return pw_forward_final(units[-1], cur, res), cur.geom
+
+
 def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[torch.Tensor] = None):
     """g: ("D", dA) unmasked gradient w.r.t. the activated output, or ("G", G, partial, rows[, pstride])
     already masked with BN-backward sums.  Returns (param grads aligned with spec.params(), g_in) where
@@ -402,10 +460,8 @@ class ChainFn(torch.autograd.Function):
             xm, geom = ops.nhwc_view(x)
             cur = Operand(xm, geom)
         if inference_tail_ok(units, infer):
-            for u in units[:-1]:
-                cur, _ = unit_forward(u, cur, training)
-            out = pw_forward_final(units[-1], cur, res=xm if residual else None)
-            return ops.nchw_from_matrix(out, cur.geom)
+            out, geom = infer_tail(units, cur, res=xm if residual else None)
+            return ops.nchw_from_matrix(out, geom)
         for u in units:
             cur, rec = unit_forward(u, cur, training)
             recs.append(rec)
@@ -459,9 +515,8 @@ class FPNFn(torch.autograd.Function):
         cur = Operand(fused, (B, Ho, Wo))
         post_recs = []
         if inference_tail_ok(post_units, infer):
-            for u in post_units[:-1]:
-                cur, _ = unit_forward(u, cur, training)
-            return ops.nchw_from_matrix(pw_forward_final(post_units[-1], cur), cur.geom)
+            out, geom = infer_tail(post_units, cur)
+            return ops.nchw_from_matrix(out, geom)
         for u in post_units:
             cur, rec = unit_forward(u, cur, training)
             post_recs.append(rec)
@@ -569,11 +624,10 @@ class ConcatFuseFn(torch.autograd.Function):
         pre = ops.materialize(cur)
         recs = []
         if inference_tail_ok(fuse_units, infer):
-            for u in fuse_units[:-1]:
-                cur, _ = unit_forward(u, cur, training)
+            out, ogeom = infer_tail(fuse_units, cur)
             pre_t = ops.nchw_from_matrix(pre, geom)
             ctx.mark_non_differentiable(pre_t)
-            return ops.nchw_from_matrix(pw_forward_final(fuse_units[-1], cur), geom), pre_t
+            return ops.nchw_from_matrix(out, ogeom), pre_t
         for u in fuse_units:
             cur, rec = unit_forward(u, cur, training)
             recs.append(rec)

@@ -415,3 +415,34 @@ def test_fpn_sum_single_pass_equals_accumulate():
         lib.call("kd_bilinear_sum_fwd", *a[0], *a[1], *a[2], P(out), B, Ho, Wo, C, stream())
         torch.cuda.synchronize()
         assert torch.equal(out, ref), n
+
+
+@pytest.mark.parametrize("case", ["ir_s1_res", "ir_s2", "ir_s2_128", "ir_t1", "ir_wide", "dwsep", "dwsep_64"])
+@pytest.mark.parametrize("hw", [(32, 32), (20, 27), (7, 9)])
+def test_dw_pw_inference_fusion_same_bits(case, hw):
+    """Eval / no-grad tails that end in (depthwise 3x3, 1x1): the one-kernel form (csrc/kd_block.hip) against the two
+    separate kernels -- the same bits, on maps that do and do not fill the 8 x 16 / 8 x 8 pixel tiles, stride 1 and 2, with
+    and without the residual, deferred and materialised depthwise inputs (camera_encoder.py:30-42, fusion_module.py:25-34)."""
+    from kdrt import ops, units as U
+    from src.models.camera_encoder import InvertedResidual
+    from src.models.fusion_module import DWSeparableConv
+    if ops.get_gemm_arithmetic() != "split":
+        pytest.skip("the fused tail exists in the split arithmetic only")
+    torch.manual_seed(1)
+    m, cin = {"ir_s1_res": (InvertedResidual(32, 32, 1, 6), 32), "ir_s2": (InvertedResidual(32, 64, 2, 6), 32),
+              "ir_s2_128": (InvertedResidual(64, 128, 2, 6), 64), "ir_t1": (InvertedResidual(32, 32, 1, 1), 32), "ir_wide": (InvertedResidual(128, 128, 1, 6), 128),
+              "dwsep": (DWSeparableConv(128, 128), 128), "dwsep_64": (DWSeparableConv(128, 64), 128)}[case]
+    _rand_state(m, 41)
+    m = m.cuda().eval()
+    x = torch.randn(2, cin, *hw, generator=torch.Generator().manual_seed(7)).cuda()
+    outs = []
+    prev = U.DW_PW_FUSED[0]
+    try:
+        for fused in (0, 2):                          # 0: two kernels, 2: one kernel for every supported shape
+            U.DW_PW_FUSED[0] = fused
+            with torch.no_grad():
+                outs.append(m(x).clone())
+    finally:
+        U.DW_PW_FUSED[0] = prev
+    assert outs[0].shape == outs[1].shape and torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
