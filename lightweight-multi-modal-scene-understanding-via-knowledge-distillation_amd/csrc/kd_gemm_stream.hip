@@ -50,6 +50,7 @@ bool stream_cfg(int K, int N, int pro, int epi, StreamCfg& c) {
     if (nbt % cand == 0 && stream_lds_bytes(K, 32 * cand, pro) <= LDS_MAX) { nb = cand; break; }
   if (nb == 0) return false;
   if (pro == 2 && epi == 2 && kb == 2 && nb == 2) return false;   // (this instance does not fit 256 registers without spills: slower)
+  if (pro == 2 && epi == 0 && kb == 4 && nb == 2) return false;   // (measured 255 vs 243 us in the KD step: the tiled kernel stays)
   const int ntiles = nbt / nb;
   // every column tile streams A again (the tiles of one slab run side by side on the same XCD, so most of it is an L2
   // hit): accept two tiles always, more only when A is the small side of the launch
@@ -105,7 +106,7 @@ int kd_gemm_stream_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {
   if (pro == 2 && epi == 0) rc = kd_stream_bwd0_dispatch(g, c.kb, c.nb, grid, st);
   else if (pro == 2 || pro == 4) rc = kd_stream_bwd2_dispatch(g, c.kb, c.nb, pro, epi, grid, st);
   else {
-// (K / 32, chunk / 32, N tile / 32, two register sets).  Measured per shape (tools/bench_stream, M = 32 frames): K = 128 and
+    // (K / 32, chunk / 32, N tile / 32, two register sets).  Measured per shape (tools/bench_stream, M = 32 frames): K = 128 and
     // the BatchNorm-prologue K = 64 layers run 5-15 % faster with 32-column chunks loaded one chunk ahead; the LiDAR layer-1
     // launch (PRO3: the streamed tensor is the 16-byte point) keeps the single whole-slab load.
 #define KD_SHAPE(KB_, KC_, NB_, DB_) if (c.kb == KB_ && c.nb == NB_) rc = fwd_dispatch<KB_, KC_, NB_, DB_>(g, pro, epi, grid, st);
@@ -116,6 +117,10 @@ int kd_gemm_stream_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {
 #undef KD_SHAPE
   }
   if (rc == 1) { const int e = kd_check_launch("kd_gemm_stream"); if (e) return -(e > 0 ? e : -e) - 1000; }   // < 0: error
+  if (rc == 0) {          // stream_cfg promised this shape (and its statistics-slab row count) to the callers: never fall back silently
+    kd_set_error("kd_gemm_stream: no instance for K=%d N=%d pro=%d epi=%d%s", g.K, g.N, pro, epi, g.addend ? " with addend" : "");
+    return -2000;
+  }
   return rc;
 }
 
