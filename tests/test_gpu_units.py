@@ -446,3 +446,20 @@ def test_dw_pw_inference_fusion_same_bits(case, hw):
         U.DW_PW_FUSED[0] = prev
     assert outs[0].shape == outs[1].shape and torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_dw_pw_inference_fusion_refuses_unsupported_shapes():
+    """kd_dw_pw_infer has no silent fallback: a shape without an instance is a KDError (the host logic asks
+    kd_dw_pw_infer_supported first and keeps the two separate kernels)."""
+    from kdrt import KDError
+    from kdrt.ops import lib, P, stream
+    assert lib.kd_dw_pw_infer_supported(384, 64, 1) == 1 and lib.kd_dw_pw_infer_supported(192, 64, 2) == 1
+    assert lib.kd_dw_pw_infer_supported(48, 64, 1) == 0 and lib.kd_dw_pw_infer_supported(64, 96, 1) == 0
+    assert lib.kd_dw_pw_infer_supported(64, 32, 2) == 0 and lib.kd_dw_pw_infer_supported(64, 64, 3) == 0
+    x = torch.zeros(1 * 8 * 8, 48, device="cuda")
+    v = torch.ones(96, device="cuda")
+    w = torch.zeros(96 * 48, device="cuda")
+    out = torch.empty(64, 96, device="cuda")
+    with pytest.raises(KDError):
+        lib.call("kd_dw_pw_infer", P(x), None, None, 0, P(w), P(v), P(v), 1, P(w), None, P(v), P(v), 1, None, 0, P(out), 96, 1, 8, 8, 48, 1, 96,
+                 stream())
