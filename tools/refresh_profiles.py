@@ -46,5 +46,7 @@ algorithmic bytes of the fwd/dgrad family in the same workload (bench.py rooflin
 reads: the column-tiled streaming launches (N = 192 / 384 / 768 as 3 / 3 / 6 tiles) stream A once per tile and not all of it hits L2,
 and the LiDAR layer-2 data gradient gathers its two per-cell tables (537 MB each) per point row.
 """)
+dec = subprocess.run([sys.executable, f"{ROOT}/tools/step_decomposition.py", f"{ROOT}/profiles/r02_bench_kernel_stats_B256.csv", "6"], capture_output=True, text=True, check=True).stdout
+open(f"{ROOT}/profiles/r02_step_decomposition.txt", "w").write("One KD step (256 frames x 80 000 points, concat teacher -> weighted student) by kernel family: rocprofv3 --kernel-trace --stats of the default bench.py,\nround-2 final code (profiles/r02_bench_kernel_stats_B256.csv: run total / 6 steps; the 'runtime copies' line is mostly the one-time model upload).\ntools/step_decomposition.py profiles/r02_bench_kernel_stats_B256.csv 6\n\n" + dec)
 print(f"family {fc} calls avg {ft / fc / 1e3:.1f} us (live {r['avg_launch_us']}); wgrad {wt / 6e6:.2f}; dw {dt / 6e6:.2f} + {zt / 6e6:.2f}; total {sum(float(x['TotalDurationNs']) for x in rows) / 6e6:.2f} ms/step")
 print(out, "ratio", pj["hbm_bytes_per_launch"] / 1e6 / alg, "hash", pj["kernel_hash"])
