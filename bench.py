@@ -202,6 +202,10 @@ def selfcheck(args, dev, teacher_fusion, student_fusion):
             total.backward()
             gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in student.parameters()))
             vals = {k: float(v) for k, v in parts.items()} | {"total": float(total.detach()), "grad_norm": float(gn)}
+            groups = {}                                       # per top-level module: a missing small group must show
+            for nm, p in student.named_parameters():
+                groups[nm.split(".")[0]] = groups.get(nm.split(".")[0], 0.0) + float((p.grad.double() ** 2).sum())
+            vals.update({"grad_norm/" + k: v ** 0.5 for k, v in groups.items()})
             res.append((vals, zs[:half].detach().clone()))
             del teacher, student, zt, mt, zs, ms, total, parts, im, pt, lb
             torch.cuda.empty_cache()
@@ -210,12 +214,12 @@ def selfcheck(args, dev, teacher_fusion, student_fusion):
     (a, za), (b, zb) = res
     import math
     finite = all(math.isfinite(x) for x in list(a.values()) + list(b.values()))
-    dl = max(abs(a[k] - b[k]) / max(1.0, abs(a[k])) for k in a if k != "grad_norm")
+    dl = max(abs(a[k] - b[k]) / max(1.0, abs(a[k])) for k in a if not k.startswith("grad_norm"))
     dz = float((za - zb).abs().max()) / max(1.0, float(za.abs().max()))
-    dg = abs(a["grad_norm"] - b["grad_norm"]) / max(a["grad_norm"], 1e-12)
+    dg = max(abs(a[k] - b[k]) / max(a[k], 1e-12) for k in a if k.startswith("grad_norm"))     # whole model and every module group
     ok = finite and dl <= 2e-5 and dz <= 1e-4 and dg <= 2e-2
     out = {"ok": bool(ok), "what": f"{2*half} frames (two copies of {half}) vs {half} frames, same seeds as the timed run",
-           "losses_at_bench_batch": {k: round(v, 6) for k, v in b.items()}, "max_rel_loss_diff": dl, "max_rel_logit_diff": dz,
+           "losses_at_bench_batch": {k: round(v, 6) for k, v in b.items() if not k.startswith("grad_norm/")}, "max_rel_loss_diff": dl, "max_rel_logit_diff": dz,
            "rel_grad_norm_diff": dg, "tolerances": {"loss": 2e-5, "logits": 1e-4, "grad_norm": 2e-2}}
     if not ok:
         raise SystemExit("bench.py self-check FAILED at the benchmarked size: " + json.dumps(out))
@@ -244,12 +248,17 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-selfcheck", action="store_true")
     ap.add_argument("--no-bf16-forward", action="store_true", help="skip the bf16-storage forward line (configs[1])")
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="--gpus 1 only: bring up RCCL with a world of one rank and run the timed steps WITH the bucketed "
+                         "gradient all-reduce (a one-rank sum: same bits), then time the same steps without it and report the delta")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
     if args.gpus > 1 and "RANK" not in os.environ:
         launch_ranks(args)                                    # never returns
+    if args.force_reducer and args.gpus != 1:
+        raise SystemExit("--force-reducer is the 1-GPU rehearsal of the RCCL path; with --gpus N > 1 the reducer always runs")
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -287,6 +296,14 @@ def main():
         if not rehearse and len({(r["host"], r["device"]) for r in gathered}) != world:
             raise SystemExit(f"bench.py: two ranks share a GPU: {gathered}")
         rank_info = {"rccl_ranks_seen": seen, "ranks": gathered}
+    elif args.force_reducer:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rank_info = {"rccl_ranks_seen": int(ones.item())}
 
     from kdrt import ops
     from kdrt.ddp import BucketedAllReduce, broadcast_module
@@ -299,12 +316,12 @@ def main():
         torch.cuda.reset_peak_memory_stats(dev)
     teacher, student = build_models(args.grid, args.teacher_fusion, args.student_fusion)
     teacher, student = teacher.to(dev).eval(), student.to(dev).train()
-    if world > 1:
+    if world > 1 or args.force_reducer:
         broadcast_module(student)
         broadcast_module(teacher)
     names = [n for n, p in student.named_parameters() if p.requires_grad]
     opt = FusedAdamW(student.parameters(), lr=1e-3, weight_decay=1e-3)          # trainer.py:56 values
-    reducer = BucketedAllReduce(opt.flat, names, n_buckets=3) if world > 1 else None
+    reducer = BucketedAllReduce(opt.flat, names, n_buckets=3, force=args.force_reducer) if (world > 1 or args.force_reducer) else None
     step = KDStep(student, teacher, opt, torch.tensor([0.4, 3.5], device=dev), T=4.0, alpha=1.0, beta=1.0,
                   reducer=reducer)
     images, pts, labels = synth_batch(args.batch, args.points, args.image, args.grid, 1234 + rank, dev, args.points_sigma)
@@ -364,6 +381,29 @@ def main():
     }
     if rank_info is not None:
         out.update(rank_info)
+    if world > 1:
+        out["cpu_baseline"] = None
+        out["bf16_forward"] = None
+        out["why_null"] = "cpu_baseline / bf16_forward / kd_step_bf16_teacher are measured by the N=1 run only (rank 0, one GPU)"
+    if args.force_reducer:
+        # the same steps WITHOUT the reducer (its hooks silenced), same models and optimiser state: the per-step cost of
+        # the three asynchronous RCCL all-reduces + wait() ordering on this box
+        reducer.enabled = False
+        plain = KDStep(student, teacher, opt, torch.tensor([0.4, 3.5], device=dev), T=4.0, alpha=1.0, beta=1.0)
+        for _ in range(max(1, args.warmup)):
+            plain(images, pts, labels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            plain(images, pts, labels)
+        torch.cuda.synchronize()
+        tp = (time.perf_counter() - t0) / args.steps
+        reducer.enabled = True
+        out["forced_reducer"] = {
+            "what": "world of ONE rank over RCCL (backend nccl): 3 async all_reduce per step on slices of the flat gradient buffer",
+            "ms_per_step_with_reducer": round(1e3 * elapsed / args.steps, 3), "ms_per_step_plain": round(1e3 * tp, 3),
+            "delta_ms_per_step": round(1e3 * (elapsed / args.steps - tp), 3),
+            "collectives_issued": reducer.collectives_issued, "bucket_bytes": [int(v.numel() * 4) for v in reducer.views]}
 
     if not args.no_roofline:
         # Live per-kernel timing of the dominant kernel family (the fp32-MFMA pointwise-conv GEMMs):
@@ -443,6 +483,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_bf16_forward and args.teacher_fusion in ("concat", "minimal"):
         # The same KD step with the frozen teacher on the bf16-storage path (KDStep(teacher_storage="bf16")): a second
         # mode reported BESIDE the fp32 headline, never instead of it.  Student forward / backward / AdamW stay fp32.
+        if reducer is not None:
+            reducer.enabled = False                            # (--force-reducer: this second-mode step runs without it)
         step_b = KDStep(student, teacher, opt, torch.tensor([0.4, 3.5], device=dev), T=4.0, alpha=1.0, beta=1.0,
                         teacher_storage="bf16")
         nb = max(3, min(args.steps, 10))
@@ -469,7 +511,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(teacher, student, args.points, args.image, args.grid, args.teacher_fusion, args.student_fusion)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -64,8 +64,13 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
                    const float* p0, const float* p1, const float* p2, const float* p3, const float* p4,
                    const float* W, const float* bias, float* C, int64_t ldc, const float* addend,
                    int64_t ldadd, int epi, const float* X, int64_t ldx, const float* esc, const float* esh,
-                   const float* emean, const float* einv, int epi_act, float* partial, int64_t M, int K, int N,
-                   const int* m_dev, void* stream);
+                   const float* emean, const float* einv, int epi_act, float* partial, int64_t partial_rows, int64_t M,
+                   int K, int N, const int* m_dev, void* stream);
+/* partial_rows (here and in kd_lidar_l1_fwd / _l1_dgrad / _l2_dgrad): the row count the caller sized `partial` for --
+ * the value kd_pwconv_stat_rows_for() / kd_lidar_l*_dgrad_stat_rows() returned -- and will pass to kd_bn_finalize_train /
+ * kd_bn_bwd_finalize.  The launch is REFUSED (status < 0) when it differs from what the kernel form selected now would
+ * write (the streaming and tiled forms write different row counts and the choice depends on process-wide switches):
+ * a slab sized for the other form is an error, never a silently wrong reduction.  Ignored when partial == NULL. */
 /* weight gradient dW[N,K] = Deff[M,N]^T . Aeff[M,K] (split-M partial tiles in `ws`, fixed-order sum).
  * d_mode 0: Deff = D; d_mode 2: Deff = al*(D*mask(X*msc+msh)) + be*X + ga.  a_mode 0/1 like pro 0/1. */
 size_t kd_pwconv_wgrad_ws_bytes(int64_t M, int N, int K);
@@ -123,13 +128,14 @@ int kd_lidar_l0_fwd(const float* pts, const float* w, const float* b, float* y, 
  * 1 store + BN statistics), data gradient (writes G0 = d/d(layer-0 output) * act0' with the BN0-backward sums; Wt = W1
  * transposed to [K0][N1]) and weight gradient.  Same kernels and coefficient conventions as kd_pwconv_gemm / _wgrad. */
 int kd_lidar_l1_fwd(const float* pts, const float* w0, const float* b0, const float* sc0, const float* sh0, int act0,
-                    const float* W1, const float* bias1, float* C, int64_t ldc, int epi, float* partial, int64_t M,
-                    int K, int N, const int* m_dev, void* stream);
+                    const float* W1, const float* bias1, float* C, int64_t ldc, int epi, float* partial,
+                    int64_t partial_rows, int64_t M, int K, int N, const int* m_dev, void* stream);
 int kd_lidar_l1_dgrad(const float* G, int64_t ldg, const float* Y1, int64_t ldy, const float* al, const float* be,
                       const float* ga, const float* msc, const float* msh, int mact, const float* Wt, float* G0,
                       int64_t ldg0, const float* pts, const float* w0, const float* b0, const float* sc0,
                       const float* sh0, const float* mean0, const float* invstd0, int act0, float* partial,
-                      float* m1_out, void* m1_ws, size_t m1_ws_bytes, int64_t M, int N1, int K0, void* stream);
+                      int64_t partial_rows, float* m1_out, void* m1_ws, size_t m1_ws_bytes, int64_t M, int N1, int K0,
+                      void* stream);
 /* m1_out (optional, [4][K0]) = sum_m G0[m][c] * pts[m][j]: the only way the layer-0 weight gradient depends on G0
  * (dW0 = al0 * m1 + sum_m (be0*y0 + ga0) * pts, the second term from kd_lidar_l0_bwd with D = NULL).  With m1_out set,
  * G0 may be NULL and the [points, K0] gradient is never written.  m1_ws: kd_lidar_l1_dgrad_ws_bytes. */
@@ -191,7 +197,7 @@ int kd_lidar_l2_dgrad(const float* Y2, int64_t ldy2, const int* rows, const floa
                       const float* al, const float* be, const float* ga, const float* sc2, const float* sh2, int act2,
                       const float* Wt, float* G1, int64_t ldg1, const float* Y1, int64_t ldy1, const float* sc1,
                       const float* sh1, const float* mean1, const float* invstd1, int act1, float* partial,
-                      int64_t M, int N2, int K1, void* stream);
+                      int64_t partial_rows, int64_t M, int N2, int K1, void* stream);
 int kd_lidar_l2_wgrad(const float* Y2, int64_t ldy2, const int* rows, const float* grid, const float* share,
                       const float* al, const float* be, const float* ga, const float* sc2, const float* sh2, int act2,
                       const float* Y1, int64_t ldy1, const float* sc1, const float* sh1, int act1, float* dW,

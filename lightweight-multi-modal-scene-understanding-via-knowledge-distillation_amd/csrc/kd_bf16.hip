@@ -402,7 +402,8 @@ int launch_gemm_bf16(GemmBfArgs& g, int ain, int epi, hipStream_t st) {
   const size_t lds = (size_t)32 * NB * g.K * 2 + (ain == 3 ? (size_t)7 * g.K * 4 : 0);
 #define KD_BCASE(A_, E_)                                                                                               \
   if (ain == A_ && epi == E_) {                                                                                        \
-    (void)hipFuncSetAttribute((const void*)pw_gemm_bf16_kernel<NB, A_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    const hipError_t le = hipFuncSetAttribute((const void*)pw_gemm_bf16_kernel<NB, A_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    KD_REQUIRE(le == hipSuccess, (int)le, "kd_bf16_pwconv: cannot raise the dynamic LDS limit to %zu B: %s", lds, hipGetErrorString(le)); \
     hipLaunchKernelGGL((pw_gemm_bf16_kernel<NB, A_, E_>), grid, dim3(64 * BW), lds, st, g);                            \
     return kd_check_launch("kd_bf16_pwconv");                                                                          \
   }

@@ -210,11 +210,9 @@ int launch(const DwPwArgs& a, hipStream_t st) {
   constexpr int HP = ((TH - 1) * STRIDE + 3) * ((TW - 1) * STRIDE + 3);
   constexpr size_t lds = (size_t)HP * XLD * 4 + (size_t)3 * MT * KC * 2 + (size_t)3 * NCB * 32 * KC * 2;
   static_assert(lds <= 160 * 1024, "the staged tiles must fit the LDS of one CU");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dw_pw_infer_kernel<STRIDE, NCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_raised{0};
+  const hipError_t e = kd_raise_dynamic_lds((const void*)dw_pw_infer_kernel<STRIDE, NCB>, lds, lds_raised);
+  KD_REQUIRE(e == hipSuccess, (int)e, "kd_dw_pw_infer: cannot raise the dynamic LDS limit to %zu B: %s", lds, hipGetErrorString(e));
   const int64_t grid = (int64_t)a.B * a.tiles_y * a.tiles_x;
   hipLaunchKernelGGL((dw_pw_infer_kernel<STRIDE, NCB>), dim3((unsigned)grid), dim3(NTHR), lds, st, a);
   return kd_check_launch("kd_dw_pw_infer");

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #define KD_ACT_NONE 0
 #define KD_ACT_RELU 1
 #define KD_ACT_RELU6 2
@@ -36,6 +38,20 @@ int kd_check_launch(const char* what);
       return (code);                       \
     }                                      \
   } while (0)
+
+// Kernels that need more than 64 KB of dynamic LDS opt in with hipFuncSetAttribute.  The attribute belongs to the
+// (function, device) pair: `raised` keeps one bit per device, so a process that drives several devices raises the limit
+// on each, and a failed call is reported instead of being remembered as done.
+static inline hipError_t kd_raise_dynamic_lds(const void* fn, size_t bytes, std::atomic<uint64_t>& raised) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (raised.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) raised.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 static inline bool kd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

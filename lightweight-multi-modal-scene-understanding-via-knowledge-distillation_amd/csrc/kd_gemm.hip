@@ -849,7 +849,27 @@ int launch_wgrad(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
 }
 
 
-int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {
+int64_t stat_rows_for(int64_t M, int K, int N, int pro, int epi) {
+  if (g_gemm_split.load(std::memory_order_relaxed)) {
+    const int r = kd_gemm_stream_stat_rows(M, K, N, pro, epi);
+    if (r > 0) return r;
+  }
+  return (M + BM - 1) / BM;
+}
+
+// partial_rows: the row count the CALLER sized its statistics slab for (and will hand to kd_bn_finalize_train /
+// kd_bn_bwd_finalize).  The two kernel forms write different row counts (one per wave / one per 128 matrix rows), and
+// which form runs depends on process-wide switches that may have moved since the caller asked: a mismatch is an error
+// here, never a silently short or stale reduction downstream (round 2's 3e-4 systematic gradient error).
+int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st, int64_t partial_rows = -1) {
+  if (g.partial && (epi == 1 || epi == 2 || epi == 3)) {
+    const int64_t want = stat_rows_for(g.M, g.K, g.N, pro, epi);
+    KD_REQUIRE(partial_rows == want, KD_ERR_ARG,
+               "GEMM statistics slab: caller sized %lld rows, this launch (M=%d K=%d N=%d pro=%d epi=%d, %s kernel) writes %lld "
+               "-- query kd_pwconv_stat_rows_for() in the same arithmetic / streaming mode as the launch",
+               (long long)partial_rows, g.M, g.K, g.N, pro, epi,
+               want == (g.M + BM - 1) / BM ? "tiled" : "streaming", (long long)want);
+  }
   const dim3 blk(256);
   g.nt_store = kd_nt_store((size_t)g.M * g.N * sizeof(float));   // (non-temporal LOADS of A measured neutral: not kept)
   // 256x64 tiles when the last column tile would be <= 64 wide (N = 32, 64, 192, ...)
@@ -919,21 +939,15 @@ int64_t kd_pwconv_stat_rows(int64_t M) { return (M + BM - 1) / BM; }
 // ... for the launch the dispatcher will actually make for (K, N, pro, epi) in the current arithmetic: the streaming
 // kernels write one row per wave (<= 1024), the tiled kernels one per 128 matrix rows.  Callers size the slab AND tell
 // kd_bn_finalize_train / kd_bn_bwd_finalize how many rows to sum with this number.
-int64_t kd_pwconv_stat_rows_for(int64_t M, int K, int N, int pro, int epi) {
-  if (g_gemm_split.load(std::memory_order_relaxed)) {
-    const int r = kd_gemm_stream_stat_rows(M, K, N, pro, epi);
-    if (r > 0) return r;
-  }
-  return (M + BM - 1) / BM;
-}
+int64_t kd_pwconv_stat_rows_for(int64_t M, int K, int N, int pro, int epi) { return stat_rows_for(M, K, N, pro, epi); }
 
 // Forward / dgrad GEMM.  See include/kd_hip.h for the argument contract.
 int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, int pro, int pro_act, const float* p0,
                    const float* p1, const float* p2, const float* p3, const float* p4, const float* W,
                    const float* bias, float* C, int64_t ldc, const float* addend, int64_t ldadd, int epi,
                    const float* X, int64_t ldx, const float* esc, const float* esh, const float* emean,
-                   const float* einv, int epi_act, float* partial, int64_t M, int K, int N, const int* m_dev,
-                   void* stream) {
+                   const float* einv, int epi_act, float* partial, int64_t partial_rows, int64_t M, int K, int N,
+                   const int* m_dev, void* stream) {
   KD_REQUIRE(A && W && C && M > 0 && K > 0 && N > 0, KD_ERR_ARG, "kd_pwconv_gemm: null pointer or empty shape");
   KD_REQUIRE(M < (int64_t)1 << 31, KD_ERR_SHAPE, "kd_pwconv_gemm: M=%lld too large", (long long)M);
   KD_REQUIRE(K % 4 == 0 && lda % 4 == 0, KD_ERR_SHAPE, "kd_pwconv_gemm: K=%d and lda=%lld must be multiples of 4", K, (long long)lda);
@@ -954,7 +968,7 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
   KD_REQUIRE(K >= 4, KD_ERR_SHAPE, "kd_pwconv_gemm: K must be >= 4");
   GemmArgs g{A, lda, A2, lda2, p0, p1, p2, p3, p4, pro, pro_act, W, bias, C, ldc, addend, ldadd,
              X, ldx, esc, esh, emean, einv, epi_act, partial, (int)M, K, N, m_dev, nullptr, nullptr};
-  return gemm_launch(g, pro, epi, (hipStream_t)stream);
+  return gemm_launch(g, pro, epi, (hipStream_t)stream, partial_rows);
 }
 
 size_t kd_pwconv_wgrad_ws_bytes(int64_t M, int N, int K) {
@@ -986,8 +1000,8 @@ int kd_pwconv_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, in
 // ---- LiDAR point-MLP layer 1 with layer 0 recomputed from the points (never materialised) -------------------
 // forward: C[M,N] = act0(bn0(l0(pts))) . W1^T + bias1; epi 0 store, 1 store + BN statistics
 int kd_lidar_l1_fwd(const float* pts, const float* w0, const float* b0, const float* sc0, const float* sh0, int act0,
-                    const float* W1, const float* bias1, float* C, int64_t ldc, int epi, float* partial, int64_t M,
-                    int K, int N, const int* m_dev, void* stream) {
+                    const float* W1, const float* bias1, float* C, int64_t ldc, int epi, float* partial,
+                    int64_t partial_rows, int64_t M, int K, int N, const int* m_dev, void* stream) {
   KD_REQUIRE(pts && w0 && b0 && sc0 && sh0 && W1 && C && M > 0 && K >= 4 && N > 0, KD_ERR_ARG, "kd_lidar_l1_fwd: bad args");
   KD_REQUIRE(M < (int64_t)1 << 31 && K % 4 == 0 && N % 4 == 0 && ldc % 4 == 0, KD_ERR_SHAPE, "kd_lidar_l1_fwd: K, N, ldc must be multiples of 4");
   KD_REQUIRE(kd_aligned16(pts) && kd_aligned16(w0) && kd_aligned16(b0) && kd_aligned16(sc0) && kd_aligned16(sh0) && kd_aligned16(W1) &&
@@ -995,7 +1009,7 @@ int kd_lidar_l1_fwd(const float* pts, const float* w0, const float* b0, const fl
   KD_REQUIRE((epi == 0 || epi == 1) && (epi == 0 || partial), KD_ERR_ARG, "kd_lidar_l1_fwd: epi must be 0, or 1 with a statistics slab");
   GemmArgs g{pts, 4, nullptr, 0, sc0, sh0, nullptr, nullptr, nullptr, 3, act0, W1, bias1, C, ldc, nullptr, 0,
              nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, partial, (int)M, K, N, m_dev, w0, b0};
-  return gemm_launch(g, 3, epi, (hipStream_t)stream);
+  return gemm_launch(g, 3, epi, (hipStream_t)stream, partial_rows);
 }
 
 // data gradient: G0[M,K0] = (dy1_eff[M,N1] . W1) * act0'(bn0(l0(pts))) with the BN0-backward sums in `partial`;
@@ -1016,7 +1030,8 @@ int kd_lidar_l1_dgrad(const float* G, int64_t ldg, const float* Y1, int64_t ldy,
                       const float* ga, const float* msc, const float* msh, int mact, const float* Wt, float* G0,
                       int64_t ldg0, const float* pts, const float* w0, const float* b0, const float* sc0,
                       const float* sh0, const float* mean0, const float* invstd0, int act0, float* partial,
-                      float* m1_out, void* m1_ws, size_t m1_ws_bytes, int64_t M, int N1, int K0, void* stream) {
+                      int64_t partial_rows, float* m1_out, void* m1_ws, size_t m1_ws_bytes, int64_t M, int N1, int K0,
+                      void* stream) {
   KD_REQUIRE(G && Y1 && al && be && ga && Wt && (G0 || m1_out) && pts && w0 && b0 && sc0 && sh0 && mean0 && invstd0 && partial && M > 0,
              KD_ERR_ARG, "kd_lidar_l1_dgrad: bad args");
   KD_REQUIRE(!m1_out || (m1_ws && m1_ws_bytes >= kd_lidar_l1_dgrad_ws_bytes(M, K0)), KD_ERR_WORKSPACE,
@@ -1029,7 +1044,7 @@ int kd_lidar_l1_dgrad(const float* G, int64_t ldg, const float* Y1, int64_t ldy,
              pts, 4, sc0, sh0, mean0, invstd0, act0, partial, (int)M, N1, K0, nullptr, w0, b0,
              nullptr, nullptr, nullptr, m1_out ? (float*)m1_ws : nullptr};
   const int sr = g_gemm_split.load(std::memory_order_relaxed) ? kd_gemm_stream_stat_rows(M, N1, K0, 2, 3) : 0;
-  const int rc = gemm_launch(g, 2, 3, (hipStream_t)stream);
+  const int rc = gemm_launch(g, 2, 3, (hipStream_t)stream, partial_rows);
   if (rc || !m1_out) return rc;
   // one slab row per wave of the streaming kernel, else per output tile: 256 rows when the output is at most 64 wide
   // (see gemm_launch), else 128
@@ -1078,8 +1093,8 @@ int kd_lidar_l2_fwd_scatter(const float* A, int64_t lda, const float* sc1, const
 int kd_lidar_l2_dgrad(const float* Y2, int64_t ldy2, const int* rows, const float* grid, const float* share, const float* al,
                       const float* be, const float* ga, const float* sc2, const float* sh2, int act2, const float* Wt,
                       float* G1, int64_t ldg1, const float* Y1, int64_t ldy1, const float* sc1, const float* sh1,
-                      const float* mean1, const float* invstd1, int act1, float* partial, int64_t M, int N2, int K1,
-                      void* stream) {
+                      const float* mean1, const float* invstd1, int act1, float* partial, int64_t partial_rows, int64_t M,
+                      int N2, int K1, void* stream) {
   KD_REQUIRE(Y2 && rows && grid && share && al && be && ga && sc2 && sh2 && Wt && G1 && Y1 && sc1 && sh1 && mean1 && invstd1 && partial && M > 0,
              KD_ERR_ARG, "kd_lidar_l2_dgrad: bad args");
   KD_REQUIRE(M < (int64_t)1 << 31 && N2 % 4 == 0 && K1 % 4 == 0 && ldy2 % 4 == 0 && ldg1 % 4 == 0 && ldy1 % 4 == 0 && N2 >= 4, KD_ERR_SHAPE,
@@ -1088,7 +1103,7 @@ int kd_lidar_l2_dgrad(const float* Y2, int64_t ldy2, const int* rows, const floa
              KD_ERR_ALIGN, "kd_lidar_l2_dgrad: 16-byte alignment");
   GemmArgs g{Y2, ldy2, nullptr, 0, al, be, ga, sc2, sh2, 4, act2, Wt, nullptr, G1, ldg1, nullptr, 0,
              Y1, ldy1, sc1, sh1, mean1, invstd1, act1, partial, (int)M, N2, K1, nullptr, nullptr, nullptr, grid, share, rows};
-  return gemm_launch(g, 4, 2, (hipStream_t)stream);
+  return gemm_launch(g, 4, 2, (hipStream_t)stream, partial_rows);
 }
 
 // weight gradient dW2[N2,K1] = dy2_eff[M,N2]^T . act1(Y1*sc1+sh1)[M,K1]

@@ -77,14 +77,13 @@ int fwd_dispatch(const GemmArgs& g, int pro, int epi, dim3 grid, hipStream_t st)
   const bool add = g.addend != nullptr;
 #define KD_SCASE(P_, E_)                                                              \
   if (pro == P_ && epi == E_) {                                                       \
-    if (add) stream_launch_one<KB, KC, NB, P_, E_, DB, true>(g, grid, st);            \
-    else stream_launch_one<KB, KC, NB, P_, E_, DB, false>(g, grid, st);               \
-    return 1;                                                                         \
+    return add ? stream_launch_one<KB, KC, NB, P_, E_, DB, true>(g, grid, st)         \
+               : stream_launch_one<KB, KC, NB, P_, E_, DB, false>(g, grid, st);       \
   }
   if constexpr (!(KB == 2 && !DB)) { KD_SCASE(0, 0) KD_SCASE(0, 1) KD_SCASE(1, 0) KD_SCASE(1, 1) KD_SCASE(0, 5) KD_SCASE(1, 5) }
   if constexpr (KB == 2 && !DB) {
-    if (!add && pro == 3 && epi == 0) { stream_launch_one<KB, KC, NB, 3, 0, DB, false>(g, grid, st); return 1; }
-    if (!add && pro == 3 && epi == 1) { stream_launch_one<KB, KC, NB, 3, 1, DB, false>(g, grid, st); return 1; }
+    if (!add && pro == 3 && epi == 0) return stream_launch_one<KB, KC, NB, 3, 0, DB, false>(g, grid, st);
+    if (!add && pro == 3 && epi == 1) return stream_launch_one<KB, KC, NB, 3, 1, DB, false>(g, grid, st);
   }
 #undef KD_SCASE
   return 0;
@@ -116,6 +115,7 @@ int kd_gemm_stream_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {
     KD_SHAPE(4, 1, 1, true) KD_SHAPE(4, 1, 2, true) KD_SHAPE(4, 1, 4, true)
 #undef KD_SHAPE
   }
+  if (rc < 0) return rc;                                                                                       // (error already set)
   if (rc == 1) { const int e = kd_check_launch("kd_gemm_stream"); if (e) return -(e > 0 ? e : -e) - 1000; }   // < 0: error
   if (rc == 0) {          // stream_cfg promised this shape (and its statistics-slab row count) to the callers: never fall back silently
     kd_set_error("kd_gemm_stream: no instance for K=%d N=%d pro=%d epi=%d%s", g.K, g.N, pro, epi, g.addend ? " with addend" : "");

@@ -8,9 +8,8 @@ int kd_stream_bwd0_dispatch(const GemmArgs& g, int kb, int nb, dim3 grid, hipStr
   const bool add = g.addend != nullptr;
 #define KD_B(KB_, KC_, NB_, DB_)                                                           \
   if (kb == KB_ && nb == NB_) {                                                            \
-    if (add) stream_launch_one<KB_, KC_, NB_, 2, 0, DB_, true>(g, grid, st);               \
-    else stream_launch_one<KB_, KC_, NB_, 2, 0, DB_, false>(g, grid, st);                  \
-    return 1;                                                                              \
+    return add ? stream_launch_one<KB_, KC_, NB_, 2, 0, DB_, true>(g, grid, st)            \
+               : stream_launch_one<KB_, KC_, NB_, 2, 0, DB_, false>(g, grid, st);          \
   }
   KD_B(1, 1, 1, false) KD_B(1, 1, 2, false) KD_B(1, 1, 4, false)
   KD_B(2, 1, 1, true) KD_B(2, 1, 2, true) KD_B(2, 1, 4, true)

@@ -7,14 +7,13 @@ using namespace kd_stream;
 
 int kd_stream_bwd2_dispatch(const GemmArgs& g, int kb, int nb, int pro, int epi, dim3 grid, hipStream_t st) {
   // LiDAR layer 2 (three streamed tensors): one register set -- two spill and run 8.1 instead of 7.3 ms
-  if (pro == 4 && epi == 2 && kb == 4 && nb == 4) { stream_launch_one<4, 1, 4, 4, 2, false, false>(g, grid, st); return 1; }
+  if (pro == 4 && epi == 2 && kb == 4 && nb == 4) return stream_launch_one<4, 1, 4, 4, 2, false, false>(g, grid, st);
   if (pro != 2 || epi != 2) return 0;
   const bool add = g.addend != nullptr;
 #define KD_B(KB_, KC_, NB_, DB_)                                                           \
   if (kb == KB_ && nb == NB_) {                                                            \
-    if (add) stream_launch_one<KB_, KC_, NB_, 2, 2, DB_, true>(g, grid, st);               \
-    else stream_launch_one<KB_, KC_, NB_, 2, 2, DB_, false>(g, grid, st);                  \
-    return 1;                                                                              \
+    return add ? stream_launch_one<KB_, KC_, NB_, 2, 2, DB_, true>(g, grid, st)            \
+               : stream_launch_one<KB_, KC_, NB_, 2, 2, DB_, false>(g, grid, st);          \
   }
   KD_B(1, 1, 1, false) KD_B(1, 1, 2, false) KD_B(1, 1, 4, false)
   KD_B(2, 1, 1, true) KD_B(2, 1, 2, true) KD_B(2, 1, 4, true)

@@ -397,15 +397,19 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
   }
 }
 
+// -> 1 launched, < 0 error (the dynamic-LDS limit of this instance could not be raised on the current device)
 template <int KB, int KC, int NB, int PRO, int EPI, bool DB = false, bool ADD = false>
-inline void stream_launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
+inline int stream_launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
   constexpr size_t lds = stream_lds_bytes(32 * KB, 32 * NB, PRO);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)pw_stream_kernel<KB, KC, NB, PRO, EPI, DB, ADD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static std::atomic<uint64_t> lds_raised{0};          // one bit per device: the attribute is per (function, device)
+  const hipError_t e = kd_raise_dynamic_lds((const void*)pw_stream_kernel<KB, KC, NB, PRO, EPI, DB, ADD>, lds, lds_raised);
+  if (e != hipSuccess) {
+    kd_set_error("kd_gemm_stream: cannot raise the dynamic LDS limit to %zu B for K=%d N=%d pro=%d epi=%d: %s", lds, g.K, g.N, PRO, EPI,
+                 hipGetErrorString(e));
+    return -3000;
   }
   hipLaunchKernelGGL((pw_stream_kernel<KB, KC, NB, PRO, EPI, DB, ADD>), grid, dim3(64 * SW), lds, st, g);
+  return 1;
 }
 
 }  // namespace kd_stream

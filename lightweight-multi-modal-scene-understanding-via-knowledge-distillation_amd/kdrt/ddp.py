@@ -15,6 +15,7 @@ reduce of the late layers flies under the camera encoder's backward.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -45,9 +46,21 @@ def distributed() -> bool:
 
 
 class BucketedAllReduce:
-    def __init__(self, flat: FlatParams, names: Optional[Sequence[str]] = None, n_buckets: int = 3, group=None):
+    """`force=True` (or KD_FORCE_REDUCER=1): issue the collectives even in a world of ONE rank.  A one-rank sum is the
+    identity, so the step must stay bit-identical to the reducer-less step -- which is how the whole RCCL path
+    (communicator, ProcessGroupNCCL's side stream and events, async work handles, `wait()` ordering before AdamW) is
+    executed and checked on a 1-GPU box (tests/test_gpu_rccl_world1.py, `bench.py --force-reducer`).
+    `enabled=False` silences the hooks (a second, reducer-less KDStep over the same parameters)."""
+
+    def __init__(self, flat: FlatParams, names: Optional[Sequence[str]] = None, n_buckets: int = 3, group=None,
+                 force: Optional[bool] = None):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = (os.environ.get("KD_FORCE_REDUCER") == "1") if force is None else bool(force)
+        if self.force and not dist.is_initialized():
+            raise RuntimeError("BucketedAllReduce(force=True) needs an initialised process group (a world of one rank is fine)")
+        self.enabled = True
+        self.collectives_issued = 0       # all-reduce calls handed to torch.distributed so far (tests / bench read it)
         n = len(flat.params)
         # bucket boundaries (parameter indices), contiguous in registration order; cut where the
         # top-level module name changes, then merged down to n_buckets of similar byte size
@@ -88,7 +101,7 @@ class BucketedAllReduce:
         # runs the parameter's AccumulateGrad node afterwards and fires this hook a second time (observed on torch 2.10:
         # every bucket was launched when HALF of its gradients had landed, and the ranks diverged).
         def hook(_p):
-            if self.seen[i]:
+            if not self.enabled or self.seen[i]:
                 return
             self.seen[i] = True
             b = self.bucket_of[i]
@@ -103,13 +116,14 @@ class BucketedAllReduce:
 
     def _launch(self, b):
         self.launch_order.append(b)
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         # Canonical async collective: ProcessGroupNCCL (RCCL) runs it on its own internal stream, ordered
         # after everything already enqueued on the current (compute) stream -- i.e. after this bucket's
         # gradient kernels -- and `work.wait()` later makes the compute stream wait for it.  The launch
         # order is the (deterministic) order in which backward finishes the buckets, identical on all ranks.
         h = dist.all_reduce(self.views[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.collectives_issued += 1
         self.handles.append(h)
 
     def finish(self):

@@ -67,12 +67,15 @@ class GraphedKDStep:
     step counter / bias corrections / learning rate are device state (kd_adamw_step_dev), BatchNorm
     running statistics are updated by the kernels themselves.
 
-    Restrictions: fixed batch shape; single GPU (the RCCL all-reduce is not captured here); call
-    `optimizer.sync_lr()` happens automatically before each replay."""
+    With a gradient reducer (data parallel) the bucketed all-reduces are captured INSIDE the graph: ProcessGroupNCCL
+    forks its collective stream off the capturing stream with an event and `work.wait()` joins it back, so the replayed
+    graph holds backward kernels -> RCCL all-reduce per bucket -> AdamW with the same dependencies as the eager step.
+    The capture then runs in "thread_local" error mode (the process group's watchdog thread polls events of earlier
+    collectives from another thread, which the default "global" mode would treat as a capture violation).
+
+    Restrictions: fixed batch shape; `optimizer.sync_lr()` happens automatically before each replay."""
 
     def __init__(self, step: KDStep, images, points, labels, warmup: int = 3):
-        if step.reducer is not None:
-            raise RuntimeError("GraphedKDStep: multi-GPU capture is not supported; use KDStep")
         self.step = step
         self.images, self.points, self.labels = images.clone(), points.clone(), labels.clone()
         side = torch.cuda.Stream()
@@ -84,7 +87,8 @@ class GraphedKDStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         step.opt.sync_lr()
-        with torch.cuda.graph(self.graph):
+        mode = {} if step.reducer is None else {"capture_error_mode": "thread_local"}
+        with torch.cuda.graph(self.graph, **mode):
             self.out = self._body()
         self.replays = 0
 
@@ -97,6 +101,7 @@ class GraphedKDStep:
         zs, ms = s.student(self.images, self.points, return_intermediates=True)
         total, parts = kd_objective(zs, ms, zt, mt, self.labels, s.cw, s.T, s.alpha, s.beta, s.ignore_index)
         total.backward()
+        s.opt.grad_scale = s.reducer.finish() if s.reducer is not None else 1.0
         s.opt.enqueue_update()
         parts["total"] = total.detach()
         parts["logits"] = zs.detach()

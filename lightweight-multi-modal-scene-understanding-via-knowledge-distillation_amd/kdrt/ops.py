@@ -193,24 +193,26 @@ def prof_scaled(rec):
 
 
 def pw_gemm(A, W, C_out, *, M, K, N, A2=None, pro=0, pro_act=0, p=(None,) * 5, bias=None, addend=None, epi=0,
-            X=None, esc=None, esh=None, emean=None, einv=None, epi_act=0, partial=None, m_dev=None):
+            X=None, esc=None, esh=None, emean=None, einv=None, epi_act=0, partial=None, partial_rows=0, m_dev=None):
+    """partial_rows: the row count `partial` was sized for (lib.kd_pwconv_stat_rows_for); the library refuses the launch
+    when the kernel form it selects now would write a different number of rows."""
     e0 = _prof_begin()
     lib.call("kd_pwconv_gemm", P(A), ld(A), P(A2), ld(A2) if A2 is not None else 0, pro, pro_act,
              P(p[0]), P(p[1]), P(p[2]), P(p[3]), P(p[4]), P(W), P(bias), P(C_out), ld(C_out),
              P(addend), ld(addend) if addend is not None else 0, epi, P(X), ld(X) if X is not None else 0,
-             P(esc), P(esh), P(emean), P(einv), epi_act, P(partial), M, K, N, P(m_dev), stream())
+             P(esc), P(esh), P(emean), P(einv), epi_act, P(partial), partial_rows, M, K, N, P(m_dev), stream())
     # algorithmic bytes: every operand tensor of the launch read or written exactly once
     _prof_end(e0, "pw_gemm", 2.0 * M * N * K,
               4.0 * (M * K * (2 if pro == 2 else 1) + M * N * (1 + (epi == 2) + (addend is not None)) + N * K), m_dev, M)
 
 
-def l1_fwd(op: Operand, W, C_out, *, bias, epi, partial, m_dev=None):
+def l1_fwd(op: Operand, W, C_out, *, bias, epi, partial, partial_rows=0, m_dev=None):
     """LiDAR layer 1 forward over a virtual layer-0 operand (pts -> layer 0 -> BN+act recomputed on load)."""
     pts, w0, b0 = op.virt
     M, K, N = pts.shape[0], w0.shape[0], W.shape[0]
     e0 = _prof_begin()
     lib.call("kd_lidar_l1_fwd", P(pts), P(w0), P(b0), P(op.sc), P(op.sh), op.act, P(W), P(bias), P(C_out), ld(C_out), epi,
-             P(partial), M, K, N, P(m_dev), stream())
+             P(partial), partial_rows, M, K, N, P(m_dev), stream())
     _prof_end(e0, "pw_gemm", 2.0 * M * N * K, 4.0 * (M * 4 + M * N + N * K), m_dev, M)
 
 
@@ -223,7 +225,7 @@ def l2_fwd_scatter(op: Operand, W, bias, bnc2: BNC, act2, cell_idx, grid, ncells
     _prof_end(e0, "pw_gemm", 2.0 * M * N * K, 4.0 * (M * K + M * 1 + N * K), m_dev, M)     # reads A + cell index; no output tensor
 
 
-def l1_dgrad(t, y, Wt, gin, *, op: Operand, al, be, ga, msc, msh, mact, partial, moments=None):
+def l1_dgrad(t, y, Wt, gin, *, op: Operand, al, be, ga, msc, msh, mact, partial, partial_rows, moments=None):
     """moments ([4, K0] tensor, optional): receives sum_m G0 * point; with it `gin` may be None (G0 is never written)."""
     pts, w0, b0 = op.virt
     M, N1, K0 = pts.shape[0], y.shape[1], w0.shape[0]
@@ -234,11 +236,11 @@ def l1_dgrad(t, y, Wt, gin, *, op: Operand, al, be, ga, msc, msh, mact, partial,
     e0 = _prof_begin()
     lib.call("kd_lidar_l1_dgrad", P(t), ld(t), P(y), ld(y), P(al), P(be), P(ga), P(msc), P(msh), mact, P(Wt), P(gin),
              ld(gin) if gin is not None else K0, P(pts), P(w0), P(b0), P(op.sc), P(op.sh), P(op.bnc.mean), P(op.bnc.invstd),
-             op.act, P(partial), P(moments), P(ws), nbytes, M, N1, K0, stream())
+             op.act, P(partial), partial_rows, P(moments), P(ws), nbytes, M, N1, K0, stream())
     _prof_end(e0, "pw_gemm", 2.0 * M * N1 * K0, 4.0 * (2 * M * N1 + (M * K0 if gin is not None else 0) + M * 4 + N1 * K0), None, M)
 
 
-def l2_dgrad(tables, out_op: Operand, Wt, gin, *, inp: Operand, al, be, ga, partial):
+def l2_dgrad(tables, out_op: Operand, Wt, gin, *, inp: Operand, al, be, ga, partial, partial_rows):
     """Data gradient of the last point-MLP layer with the scatter-max gradient rebuilt from (row_sorted, grid, share)."""
     rows_t, grid, share = tables
     y = out_op.raw
@@ -247,7 +249,7 @@ def l2_dgrad(tables, out_op: Operand, Wt, gin, *, inp: Operand, al, be, ga, part
     t0 = _prof_begin()
     lib.call("kd_lidar_l2_dgrad", P(y), ld(y), P(rows_t), P(grid), P(share), P(al), P(be), P(ga), P(out_op.sc), P(out_op.sh),
              out_op.act, P(Wt), P(gin), ld(gin), P(inp.raw), ld(inp.raw), P(inp.sc), P(inp.sh), P(inp.bnc.mean), P(inp.bnc.invstd),
-             inp.act, P(partial), M, N, K, stream())
+             inp.act, P(partial), partial_rows, M, N, K, stream())
     # algorithmic traffic: Y2 in, Y1 in (epilogue mask), G1 out; the tables are cache-resident (one row per ~12 points)
     _prof_end(t0, "pw_gemm", 2.0 * M * N * K, 4.0 * (M * N + 2 * M * K + M + N * K), None, M)
 

@@ -89,10 +89,11 @@ def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] 
             rows = lib.kd_pwconv_stat_rows_for(M, K, N, pro, 1)         # streaming kernels: one row per wave; tiled: per 128 rows
             partial = torch.empty(rows * 2 * N, device=dev, dtype=torch.float32)
         if inp.virt is not None:
-            ops.l1_fwd(inp, w, y, bias=b, epi=1 if training else 0, partial=partial, m_dev=m_dev)
+            ops.l1_fwd(inp, w, y, bias=b, epi=1 if training else 0, partial=partial, partial_rows=rows, m_dev=m_dev)
         else:
             ops.pw_gemm(inp.raw, w, y, M=M, K=K, N=N, pro=1 if inp.bnc is not None else 0, pro_act=inp.act,
-                        p=(inp.sc, inp.sh, None, None, None), bias=b, epi=1 if training else 0, partial=partial, m_dev=m_dev)
+                        p=(inp.sc, inp.sh, None, None, None), bias=b, epi=1 if training else 0, partial=partial, partial_rows=rows,
+                        m_dev=m_dev)
         rec.out_geom = inp.geom
         rec.bnc = _coeffs(spec, partial, rows, N, M, training, bnc, dev)
     elif kind == "dw":
@@ -315,17 +316,18 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
                     # layer 0's weight gradient is linear in G0: the GEMM epilogue leaves sum G0 * point and G0 is never written
                     m1 = torch.empty(4, K, device=dev, dtype=torch.float32)
                     ops.l1_dgrad(t, y, Wt, None, op=inp, al=al, be=be, ga=ga, msc=msc, msh=msh, mact=mact, partial=part_in,
-                                 moments=m1)
+                                 partial_rows=rows_in, moments=m1)
                     g_in = ("GM", m1, part_in, rows_in)
                 else:
                     gin = torch.empty(M, K, device=dev, dtype=torch.float32)
-                    ops.l1_dgrad(t, y, Wt, gin, op=inp, al=al, be=be, ga=ga, msc=msc, msh=msh, mact=mact, partial=part_in)
+                    ops.l1_dgrad(t, y, Wt, gin, op=inp, al=al, be=be, ga=ga, msc=msc, msh=msh, mact=mact, partial=part_in,
+                                 partial_rows=rows_in)
                     g_in = ("G", gin, part_in, rows_in)
             elif tables:
                 gin = torch.empty(M, K, device=dev, dtype=torch.float32)
                 rows_in = lib.kd_lidar_l2_dgrad_stat_rows(M, N, K)
                 part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
-                ops.l2_dgrad(t, out_op, Wt, gin, inp=inp, al=al, be=be, ga=ga, partial=part_in)
+                ops.l2_dgrad(t, out_op, Wt, gin, inp=inp, al=al, be=be, ga=ga, partial=part_in, partial_rows=rows_in)
                 g_in = ("G", gin, part_in, rows_in)
             elif inp.bnc is not None:
                 gin = torch.empty(M, K, device=dev, dtype=torch.float32)
@@ -333,7 +335,7 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
                 part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
                 ops.pw_gemm(t, Wt, gin, M=M, K=N, N=K, A2=y, pro=2, pro_act=mact, p=(al, be, ga, msc, msh),
                             addend=addend, epi=2, X=inp.raw, esc=inp.sc, esh=inp.sh, emean=inp.bnc.mean,
-                            einv=inp.bnc.invstd, epi_act=inp.act, partial=part_in)
+                            einv=inp.bnc.invstd, epi_act=inp.act, partial=part_in, partial_rows=rows_in)
                 g_in = ("G", gin, part_in, rows_in)
             else:
                 dx = torch.empty(M, K, device=dev, dtype=torch.float32)
@@ -412,7 +414,7 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
                 rows_in = lib.kd_pwconv_stat_rows_for(inp.M, N16, Cin, 0, 2)
                 part_in = torch.empty(rows_in * 2 * Cin, device=dev, dtype=torch.float32)
                 ops.pw_gemm(dcol, Wd, gin, M=inp.M, K=N16, N=Cin, addend=addend, epi=2, X=inp.raw, esc=inp.sc, esh=inp.sh,
-                            emean=inp.bnc.mean, einv=inp.bnc.invstd, epi_act=inp.act, partial=part_in)
+                            emean=inp.bnc.mean, einv=inp.bnc.invstd, epi_act=inp.act, partial=part_in, partial_rows=rows_in)
                 g_in = ("G", gin, part_in, rows_in)
             else:
                 dx = torch.empty(inp.M, Cin, device=dev, dtype=torch.float32)
@@ -695,11 +697,11 @@ class WeightedFuseFn(torch.autograd.Function):
         dw1, w1_dir = gradsink.out_for(ctx.w1)
         ops.pw_wgrad(gh, cat, dw1, M=M, N=C, K=2 * C, d_mode=0, a_mode=1, a_act=ACT_RELU, asc=comb.scale, ash=comb.shift)
         w1t = ops.transpose(ctx.w1.view(C, 2 * C))
-        rows = lib.kd_pwconv_stat_rows(M)
+        rows = lib.kd_pwconv_stat_rows_for(M, C, 2 * C, 0, 2)           # (reduction width C, output width 2C)
         partial = torch.empty(rows * 2 * 2 * C, device=dev, dtype=torch.float32)
         gcat = torch.empty(M, 2 * C, device=dev, dtype=torch.float32)
         ops.pw_gemm(gh, w1t, gcat, M=M, K=C, N=2 * C, pro=0, addend=dcat, epi=2, X=cat, esc=comb.scale, esh=comb.shift,
-                    emean=comb.mean, einv=comb.invstd, epi_act=ACT_RELU, partial=partial)
+                    emean=comb.mean, einv=comb.invstd, epi_act=ACT_RELU, partial=partial, partial_rows=rows)
         dcam, dlid, pg_c, pg_l = _proj_pair_backward(ctx, gcat, partial, rows, C, C, ctx.needs_input_grad[0],
                                                      ctx.needs_input_grad[1])
         return (dcam, dlid, None, None, None, gradsink.finish(ctx.w1, dw1, w1_dir), db1, dw2, db2, *pg_c, *pg_l)

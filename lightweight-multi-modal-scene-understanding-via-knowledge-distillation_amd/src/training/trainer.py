@@ -36,9 +36,10 @@ class SegmentationMetrics:
     """Confusion-matrix mIoU.  `update` accepts logits [B,C,H,W] and int64 targets [B,H,W] on the GPU
     (integer-exact device kernel) -- same semantics as the reference's numpy loop."""
 
-    def __init__(self, num_classes=2, ignore_index=-1):
+    def __init__(self, num_classes=2, ignore_index=-1, device=None):
         self.num_classes = num_classes
         self.ignore_index = ignore_index
+        self.device = device             # only needed by a data-parallel rank that never sees a batch (see _sync)
         self.reset()
 
     def reset(self):
@@ -49,12 +50,21 @@ class SegmentationMetrics:
         self._dev, _ = confusion(preds, targets, self.num_classes, self.ignore_index, out=self._dev)
 
     def _sync(self):
-        if self._dev is not None:
-            g = self._dev
-            if distributed():                       # data parallel: every rank counted its own shard of the frames
-                g = g.clone()                       # (the device matrix keeps this rank's own counts)
-                dist.all_reduce(g)
+        if distributed():
+            # Data parallel: every rank counted its own shard of the frames.  EVERY rank takes part in the all-reduce,
+            # also one whose shard was empty (fewer validation frames than ranks): a skipped collective would pair with
+            # the next one the other ranks issue -- a hang or silently mixed tensors.
+            if self._dev is not None:
+                g = self._dev.clone()               # (the device matrix keeps this rank's own counts)
+            else:
+                dev = self.device
+                if dev is None:
+                    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+                g = torch.zeros(self.num_classes, self.num_classes, device=dev, dtype=torch.int64)
+            dist.all_reduce(g)
             self.confusion = g.cpu().numpy().astype(np.int64)
+        elif self._dev is not None:
+            self.confusion = self._dev.cpu().numpy().astype(np.int64)
 
     def compute(self):
         self._sync()
@@ -78,7 +88,6 @@ class Trainer:
         self.num_epochs = num_epochs
         if class_weights is not None:
             class_weights = torch.FloatTensor(class_weights).to(device)
-            print(f"Using class weights: {class_weights.tolist()}")
         self.class_weights = class_weights
         self.ignore_index = -1
         self.criterion = lambda logits, seg: seg_loss(logits, seg, self.class_weights, self.ignore_index)[0]
@@ -92,6 +101,8 @@ class Trainer:
             names = [n for n, p in model.named_parameters() if p.requires_grad]
             self.reducer = BucketedAllReduce(self.optimizer.flat, names, n_buckets=3)
         self.is_main = not distributed() or dist.get_rank() == 0
+        if class_weights is not None:
+            self._log(f"Using class weights: {class_weights.tolist()}")
         self.sink = gradsink.install(self.optimizer.flat, self.reducer)   # backward kernels write into the flat grad buffer
         self.save_dir = save_dir
         self.epoch = 0
@@ -100,6 +111,12 @@ class Trainer:
         self.best_miou = 0.0
         self.history_path = os.path.join(save_dir, "training_history.json")
         self.history = {"train_loss": [], "train_miou": [], "val_loss": [], "val_miou": [], "lr": []}
+
+    def _log(self, *a, **k):
+        """Console output of the training loop: rank 0 only under data parallelism (errors and warnings of the other
+        ranks still reach their own stderr -- nothing is patched process-wide)."""
+        if self.is_main:
+            print(*a, **k)
 
     # one optimisation step; overridden by KDTrainer
     def _step(self, imgs, pts, seg):
@@ -123,7 +140,7 @@ class Trainer:
 
     def train_epoch(self):
         self.model.train()
-        metrics = SegmentationMetrics(num_classes=2)
+        metrics = SegmentationMetrics(num_classes=2, device=self.device)
         total = torch.zeros((), device=self.device)
         if hasattr(self.train_loader, "set_epoch"):       # rank-sharded loaders reshuffle per epoch, identically on all ranks
             self.train_loader.set_epoch(self.epoch)
@@ -140,7 +157,7 @@ class Trainer:
         self.model.eval()
         if distributed():
             broadcast_buffers(self.model)       # all ranks evaluate rank 0's BatchNorm statistics (the model that is saved)
-        metrics = SegmentationMetrics(num_classes=2)
+        metrics = SegmentationMetrics(num_classes=2, device=self.device)
         total = torch.zeros((), device=self.device)
         with torch.no_grad():
             for batch in tqdm(self.val_loader, desc="Val", disable=not self.is_main):
@@ -169,7 +186,7 @@ class Trainer:
             self.scheduler.load_state_dict(ckpt["scheduler_state"])
         self.best_miou = ckpt.get("val_miou", 0.0)
         start_epoch = ckpt.get("epoch", 0) + 1
-        print(f"Resumed from {path}, starting at epoch {start_epoch}, best mIoU {self.best_miou:.4f}")
+        self._log(f"Resumed from {path}, starting at epoch {start_epoch}, best mIoU {self.best_miou:.4f}")
         return start_epoch
 
     def update_history(self, train_loss, train_miou, val_loss, val_miou, lr):
@@ -181,33 +198,33 @@ class Trainer:
                 json.dump(self.history, f, indent=2)
 
     def train(self, start_epoch=0):
-        print(f"\nStarting training from epoch {start_epoch + 1}/{self.num_epochs}")
-        print("=" * 60)
+        self._log(f"\nStarting training from epoch {start_epoch + 1}/{self.num_epochs}")
+        self._log("=" * 60)
         for epoch in range(start_epoch, self.num_epochs):
             self.epoch = epoch
-            print(f"\nEpoch {epoch+1}/{self.num_epochs}")
-            print("-" * 60)
+            self._log(f"\nEpoch {epoch+1}/{self.num_epochs}")
+            self._log("-" * 60)
             train_loss, train_metrics = self.train_epoch()
             val_loss, val_metrics = self.validate()
             self.scheduler.step()
             current_lr = self.optimizer.param_groups[0]["lr"]
             train_miou, val_miou = train_metrics["miou"], val_metrics["miou"]
-            print("\nResults:")
-            print(f"  Train Loss: {train_loss:.4f} | Train mIoU: {train_miou:.4f}")
-            print(f"  Val Loss:   {val_loss:.4f} | Val mIoU:   {val_miou:.4f}")
-            print(f"  Learning Rate: {current_lr:.6f}")
-            print("\n  Per-class IoU (Val):")
+            self._log("\nResults:")
+            self._log(f"  Train Loss: {train_loss:.4f} | Train mIoU: {train_miou:.4f}")
+            self._log(f"  Val Loss:   {val_loss:.4f} | Val mIoU:   {val_miou:.4f}")
+            self._log(f"  Learning Rate: {current_lr:.6f}")
+            self._log("\n  Per-class IoU (Val):")
             for name, iou in zip(["Background", "Drivable"], val_metrics["class_iou"]):
-                print(f"    {name:12s}: {iou:.4f}")
+                self._log(f"    {name:12s}: {iou:.4f}")
             self.update_history(train_loss, train_miou, val_loss, val_miou, current_lr)
             is_best = val_miou > self.best_miou
             if is_best:
                 self.best_miou = val_miou
-                print(f"  New best mIoU: {val_miou:.4f}")
+                self._log(f"  New best mIoU: {val_miou:.4f}")
             self.save_checkpoint(epoch, val_miou, is_best=is_best)
-        print("\n" + "=" * 60)
-        print(f"Training completed! Best validation mIoU: {self.best_miou:.4f}")
-        print("=" * 60)
+        self._log("\n" + "=" * 60)
+        self._log(f"Training completed! Best validation mIoU: {self.best_miou:.4f}")
+        self._log("=" * 60)
         return self.best_miou
 
 

@@ -22,6 +22,14 @@ from src.models.fusion_module import CompleteSegmentationModel
 from src.models.lidar_encoder import LiDAREncoder
 from src.training.trainer import KDTrainer, Trainer
 
+_MAIN = [True]
+
+
+def log(*a, **k):
+    """The script's own console output: one console under torchrun (rank 0); other ranks keep print() for diagnostics."""
+    if _MAIN[0]:
+        print(*a, **k)
+
 
 def build_model(fusion_type, fusion_out_channels, device, num_classes=2):
     cam_enc = TwinLiteEncoder(return_multiscale=True)
@@ -33,13 +41,13 @@ def build_model(fusion_type, fusion_out_channels, device, num_classes=2):
 
 
 def train_fusion_variant(fusion_type, fusion_out_channels, root, train_scenes, val_scenes, device):
-    print(f"\n{'='*80}\nTRAINING: {fusion_type.upper()} FUSION\n{'='*80}")
+    log(f"\n{'='*80}\nTRAINING: {fusion_type.upper()} FUSION\n{'='*80}")
     train_loader, val_loader = create_pandaset_dataloaders(
         root=root, train_scenes=train_scenes, val_scenes=val_scenes,
         batch_size=int(os.environ.get("KD_BATCH_SIZE", 4)), num_workers=2, verbose=False)
     model = build_model(fusion_type, fusion_out_channels, device)
     summary = model.get_architecture_summary()
-    print(f"\nModel: {fusion_type}\n  Total params: {summary['total_params']}\n  Fusion params: {summary['fusion_params']}")
+    log(f"\nModel: {fusion_type}\n  Total params: {summary['total_params']}\n  Fusion params: {summary['fusion_params']}")
     kw = dict(lr=1e-3, weight_decay=1e-3, save_dir=f"checkpoints/fusion_ablation_{fusion_type}",
               class_weights=[0.4, 3.5], num_epochs=int(os.environ.get("KD_EPOCHS", 20)))
     teacher_ckpt = os.environ.get("KD_TEACHER")
@@ -63,30 +71,31 @@ def main():
         rehearse = os.environ.get("KD_REHEARSE_ON_ONE_GPU") == "1"
         torch.cuda.set_device(0 if rehearse else int(os.environ.get("LOCAL_RANK", 0)))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if rehearse else "nccl")   # the loaders shard the frames over ranks themselves
+        if rehearse:
+            dist.init_process_group("gloo")                       # the loaders shard the frames over ranks themselves
+        else:                                                     # "nccl" is RCCL on ROCm; bind the communicator to this rank's GPU
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
     device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     main_rank = not dist.is_initialized() or dist.get_rank() == 0
-    if not main_rank:                       # one console: the other ranks train silently
-        import builtins
-        builtins.print = lambda *a, **k: None
-    print(f"\n{'='*80}\nFUSION ABLATION STUDY - 2-CLASS DRIVABLE AREA SEGMENTATION\n{'='*80}")
-    print(f"Device: {device}\nScenes: {len(train_scenes)} train, {len(val_scenes)} val\n{'='*80}\n")
+    _MAIN[0] = main_rank
+    log(f"\n{'='*80}\nFUSION ABLATION STUDY - 2-CLASS DRIVABLE AREA SEGMENTATION\n{'='*80}")
+    log(f"Device: {device}\nScenes: {len(train_scenes)} train, {len(val_scenes)} val\n{'='*80}\n")
     results = {}
     for fusion_type, out_ch in (("concat", 256), ("minimal", 128), ("weighted", 128)):
         miou, total_params, fusion_params = train_fusion_variant(fusion_type, out_ch, root, train_scenes, val_scenes, device)
         results[fusion_type] = {"miou": miou, "total_params": total_params, "fusion_params": fusion_params}
-    print(f"\n{'='*80}\nFUSION ABLATION RESULTS\n{'='*80}")
-    print(f"{'Fusion':<12} {'mIoU':>8} {'Total Params':>15} {'Fusion Params':>15}\n" + "-" * 80)
+    log(f"\n{'='*80}\nFUSION ABLATION RESULTS\n{'='*80}")
+    log(f"{'Fusion':<12} {'mIoU':>8} {'Total Params':>15} {'Fusion Params':>15}\n" + "-" * 80)
     for ftype, data in results.items():
-        print(f"{ftype:<12} {data['miou']:>8.4f} {data['total_params']:>15} {data['fusion_params']:>15}")
+        log(f"{ftype:<12} {data['miou']:>8.4f} {data['total_params']:>15} {data['fusion_params']:>15}")
     best = max(results.items(), key=lambda x: x[1]["miou"])
-    print(f"\n{'='*80}\nBEST FUSION: {best[0].upper()}\n  mIoU: {best[1]['miou']:.4f}\n  Total params: {best[1]['total_params']}\n{'='*80}\n")
+    log(f"\n{'='*80}\nBEST FUSION: {best[0].upper()}\n  mIoU: {best[1]['miou']:.4f}\n  Total params: {best[1]['total_params']}\n{'='*80}\n")
     if main_rank:
         with open("fusion_ablation_results.json", "w") as f:
             json.dump(results, f, indent=2)
-        print("Results saved to fusion_ablation_results.json")
+        log("Results saved to fusion_ablation_results.json")
     if dist.is_initialized():
-        dist.barrier()
+        dist.barrier(device_ids=[torch.cuda.current_device()]) if dist.get_backend() == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 

@@ -86,3 +86,54 @@ def grads_match(got: torch.Tensor, want: torch.Tensor, l2_tol=1e-2, max_tol=2e-2
         l2_tol, max_tol = 5e-2, 5e-2   # no channel can be dropped, a single flip shows at full weight
     ok = l2 <= l2_tol and mx <= max_tol and l2_all <= gross_tol
     return ok, f"relL2(inliers)={l2:.2e} max(inliers)/scale={mx:.2e} relL2(all)={l2_all:.2e} scale={scale:.2e}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Gradient accuracy against the float64 oracle (no flip-tolerant comparison): shared by tests/test_gpu_parity.py and the
+# seed scan tools/diag_fp64_seeds.py.
+FP64_B, FP64_HW, FP64_N, FP64_G = 2, 64, 512, 16
+
+
+def fp64_oracle_grads(student_fusion: str, objective: str, seed: int, dtype):
+    """Gradients of one training step of the CPU oracle evaluated in `dtype`.  objective: "kd" = concat teacher (eval,
+    state seed 11) -> student (state seed 12), CE + T^2 KL + feature MSE; "ce" = the reference's plain weighted-CE step
+    (trainer.py:86-90) on the same student."""
+    images, pts, labels = O.make_inputs(FP64_B, FP64_HW, FP64_N, FP64_G, seed, pad_tail=40)
+    cw = torch.tensor([0.4, 3.5])
+    G = FP64_G
+    cast = lambda st: {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in st.items()}
+    s_st = O.clone_state(cast(O.randomize_state(state_template(student_fusion), 12)), requires_grad=True)
+    zs, ms = O.complete_model(images.to(dtype), pts.to(dtype), s_st, fusion_type=student_fusion, grid=(G, G), training=True)
+    if objective == "kd":
+        t_st = cast(O.randomize_state(state_template("concat"), 11))
+        with torch.no_grad():
+            zt, mt = O.complete_model(images.to(dtype), pts.to(dtype), t_st, fusion_type="concat", grid=(G, G), training=False)
+        total, _ = O.kd_loss(zs, ms, zt, mt, labels, cw.to(dtype), 4.0, 1.0, 1.0)
+    else:
+        total = O.weighted_ce(zs, labels, cw.to(dtype))
+    total.backward()
+    return {k: v.grad.double() for k, v in s_st.items() if v.grad is not None}
+
+
+def fp64_gpu_grads(student_fusion: str, objective: str, seed: int):
+    from kdrt.losses import kd_objective, seg_loss
+    images, pts, labels = O.make_inputs(FP64_B, FP64_HW, FP64_N, FP64_G, seed, pad_tail=40)
+    cw = torch.tensor([0.4, 3.5]).cuda()
+    student = build_product(student_fusion, FP64_G); load_random_state(student, student_fusion, 12); student.train()
+    zs, ms = student(images.cuda(), pts.cuda(), return_intermediates=True)
+    if objective == "kd":
+        teacher = build_product("concat", FP64_G); load_random_state(teacher, "concat", 11); teacher.eval()
+        with torch.no_grad():
+            zt, mt = teacher(images.cuda(), pts.cuda(), return_intermediates=True)
+        total, _ = kd_objective(zs, ms, zt, mt, labels.cuda(), cw, 4.0, 1.0, 1.0, -1)
+    else:
+        total, _ = seg_loss(zs, labels.cuda(), cw)
+    total.backward()
+    return {n: p.grad.detach().double().cpu() for n, p in student.named_parameters()}
+
+
+def fp64_rel_errors(g64, g):
+    """Sorted per-tensor relative L2 distances to the float64 gradients, over the tensors whose gradient is not noise."""
+    gmax = max(v.abs().max().item() for v in g64.values())
+    keys = [k for k in g64 if g64[k].norm().item() > 1e-5 * gmax * g64[k].numel() ** 0.5]
+    return sorted(((g[k].double().cpu() - g64[k]).norm() / g64[k].norm()).item() for k in keys)

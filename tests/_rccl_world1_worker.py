@@ -1,0 +1,128 @@
+"""Worker of tests/test_gpu_rccl_world1.py: ONE rank, backend "nccl" (= RCCL on ROCm), on cuda:0.
+
+A 1-GPU box cannot host two RCCL ranks (RCCL refuses two ranks on one device), but a world of one rank still runs the
+whole product path that `bench.py --gpus N` / the trainers use at N > 1: `init_process_group("nccl", device_id=...)`,
+the RCCL communicator, ProcessGroupNCCL's collective stream and events, `broadcast_module`, asynchronous `all_reduce`
+on contiguous slices of the flat gradient buffer launched from the gradient sink in backward-completion order, and
+`work.wait()` ordering the fused AdamW kernel after them.  A one-rank sum is the identity, so with the reducer FORCED
+(kdrt.ddp.BucketedAllReduce(force=True)) every step must leave exactly the bits of the reducer-less step.
+Also: the same step captured into a hipGraph with the collectives inside (kdrt.kd.GraphedKDStep)."""
+import json
+import os
+import sys
+import warnings
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (os.path.join(ROOT, "lightweight-multi-modal-scene-understanding-via-knowledge-distillation_amd"), os.path.join(ROOT, "oracle"), HERE):
+    sys.path.insert(0, p)
+
+import kd_oracle as O  # noqa: E402
+from _gpu_util import build_product, load_random_state  # noqa: E402
+from kdrt.ddp import BucketedAllReduce, broadcast_module  # noqa: E402
+from kdrt.kd import GraphedKDStep, KDStep  # noqa: E402
+from kdrt.optim import FusedAdamW  # noqa: E402
+
+B, HW, N, G = 2, 64, 512, 16
+STEPS = 3
+
+
+def models(student_fusion):
+    teacher = build_product("concat", G); load_random_state(teacher, "concat", 11); teacher.eval()
+    student = build_product(student_fusion, G); load_random_state(student, student_fusion, 12); student.train()
+    return teacher, student
+
+
+def batch(i):
+    return tuple(t.cuda() for t in O.make_inputs(B, HW, N, G, 300 + i, pad_tail=40))
+
+
+def snapshot(student, opt):
+    bufs = torch.cat([b.detach().double().reshape(-1) for b in student.buffers()])
+    return opt.flat.data.clone(), opt.flat.grad.clone(), opt.exp_avg_sq.clone(), bufs
+
+
+def same(a, b):
+    return all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def run(student_fusion, forced, graphed=False):
+    teacher, student = models(student_fusion)
+    if forced:
+        broadcast_module(student)
+        broadcast_module(teacher)
+    opt = FusedAdamW(student.parameters(), lr=1e-3, weight_decay=1e-3)
+    names = [n for n, p in student.named_parameters() if p.requires_grad]
+    red = BucketedAllReduce(opt.flat, names, n_buckets=3, force=True) if forced else None
+    step = KDStep(student, teacher, opt, torch.tensor([0.4, 3.5]).cuda(), reducer=red)
+    orders, syncs, snaps = [], 0, []
+    if graphed:
+        # warm-up steps run eagerly on batch(0) inside the constructor; the capture itself executes nothing
+        g = GraphedKDStep(step, *batch(0), warmup=STEPS)
+        orders.append(list(red.launch_order) if red is not None else [])
+        for i in range(2):
+            g(*batch(1 + i))
+        torch.cuda.synchronize()
+        return {"snap": snapshot(student, opt), "collectives": red.collectives_issued if red is not None else 0}
+    for i in range(STEPS):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            if i > 0:
+                torch.cuda.set_sync_debug_mode("warn")          # a host-synchronising torch call inside the step would warn
+            if red is not None:
+                red.launch_order = []
+            launch_log = []
+            if red is not None:
+                orig = red._launch
+                red._launch = lambda b, o=orig, log=launch_log: (log.append(b), o(b))[1]
+            step(*batch(i))
+            if red is not None:
+                red._launch = orig
+            torch.cuda.set_sync_debug_mode("default")
+            syncs += sum("synchroniz" in str(x.message).lower() for x in w)
+        orders.append(launch_log)
+        torch.cuda.synchronize()
+        snaps.append(snapshot(student, opt))
+    return {"snaps": snaps, "orders": orders, "syncs": syncs, "collectives": red.collectives_issued if red is not None else 0}
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)         # "nccl" is RCCL on ROCm
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    res = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ranks_seen": int(ones.item())}
+    for fusion in ("weighted", "minimal"):
+        plain = run(fusion, forced=False)
+        forced = run(fusion, forced=True)
+        res[fusion] = {
+            "bit_identical_steps": [same(a, b) for a, b in zip(plain["snaps"], forced["snaps"])],
+            "orders": forced["orders"], "collectives": forced["collectives"],
+            "host_syncs_plain": plain["syncs"], "host_syncs_forced": forced["syncs"],
+        }
+    # hipGraph capture with the collectives inside
+    try:
+        want = None
+        teacher, student = models("weighted")
+        opt = FusedAdamW(student.parameters(), lr=1e-3, weight_decay=1e-3)
+        step = KDStep(student, teacher, opt, torch.tensor([0.4, 3.5]).cuda())
+        for i in [0] * STEPS + [1, 2]:
+            step(*batch(i))
+        torch.cuda.synchronize()
+        want = snapshot(student, opt)
+        got = run("weighted", forced=True, graphed=True)
+        res["graph"] = {"ok": True, "bit_identical": same(want, got["snap"]), "collectives_at_capture_and_warmup": got["collectives"]}
+    except Exception as e:          # reported, judged by the test
+        res["graph"] = {"ok": False, "error": f"{type(e).__name__}: {e}"[:2000]}
+    with open(os.environ["KD_RCCL_OUT"], "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,7 +36,7 @@ def test_version_arch_and_queries():
 def test_argument_errors_are_reported_not_thrown():
     from kdrt.lib import KDError, lib
     rc = lib.kd_pwconv_gemm(None, 0, None, 0, 0, 0, None, None, None, None, None, None, None, None, 0, None, 0, 0, None, 0,
-                            None, None, None, None, 0, None, 0, 0, 0, None, None)
+                            None, None, None, None, 0, None, 0, 0, 0, 0, None, None)
     assert rc < 0
     assert b"kd_pwconv_gemm" in lib.kd_last_error_string()
     with pytest.raises(KDError):

@@ -270,3 +270,85 @@ def test_bucket_fires_only_after_all_its_gradients_with_sink_and_autograd_hooks(
             assert torch.equal(flat.grad, torch.full_like(flat.grad, 3.0))
     finally:
         gradsink.uninstall()
+
+
+def _metrics_worker(rank, world, port, q):
+    """Validation with FEWER frames than ranks: rank 1's shard is empty, it never calls update(), and it must still take
+    part in the confusion-matrix all-reduce -- otherwise its next collective (here a broadcast) pairs with rank 0's
+    all-reduce: a hang or mixed tensors."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "lightweight-multi-modal-scene-understanding-via-knowledge-distillation_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from src.data_loading.pandaset_dataset import RankShardSampler
+    from src.training.trainer import SegmentationMetrics
+    n_val = 1                                                        # < world
+    mine = list(RankShardSampler(n_val, rank, world, shuffle=False, equal=False))
+    m = SegmentationMetrics(num_classes=2, device=torch.device("cpu"))
+    for _ in mine:                                                   # what update() leaves behind (its kernel needs a GPU)
+        m._dev = torch.tensor([[5, 1], [2, 8]], dtype=torch.int64)
+    res = m.compute()
+    nxt = torch.tensor([float(rank + 7)])                            # the collective that follows in Trainer.train()
+    dist.broadcast(nxt, src=0)
+    q.put((rank, len(mine), m.confusion.tolist(), res["miou"], float(nxt)))
+    dist.destroy_process_group()
+
+
+def test_metrics_allreduce_with_an_empty_validation_shard():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_metrics_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [1, 0]                             # rank 1 saw no frame
+    for _, _, conf, miou, nxt in res:
+        assert conf == [[5, 1], [2, 8]] and nxt == 7.0               # same matrix everywhere; the next collective pairs up
+        assert abs(miou - (5 / 8 + 8 / 11) / 2) < 1e-12
+
+
+def _forced_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "lightweight-multi-modal-scene-understanding-via-knowledge-distillation_amd"))
+    from kdrt.ddp import BucketedAllReduce
+    from kdrt.optim import FlatParams
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ps = [torch.nn.Parameter(torch.randn(5, generator=torch.Generator().manual_seed(i))) for i in range(4)]
+    flat = FlatParams(ps)
+    red = BucketedAllReduce(flat, ["a.w", "a.b", "b.w", "b.b"], n_buckets=2, force=True)
+    out = []
+    for enabled in (True, False, True):
+        red.enabled = enabled
+        flat.zero_grad()
+        sum((p * p).sum() for p in ps).backward()
+        issued = red.collectives_issued
+        scale = red.finish() if enabled else None
+        out.append((enabled, issued, scale, torch.equal(flat.grad[:5], 2 * ps[0].detach())))
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def test_forced_reducer_in_a_world_of_one_rank_issues_collectives_and_can_be_silenced():
+    """kdrt.ddp.BucketedAllReduce(force=True): the collectives run even with ONE rank (how the RCCL path is executed on
+    a 1-GPU box); `enabled = False` silences the hooks for a reducer-less step over the same parameters."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    out = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert out == [(True, 2, 1.0, True), (False, 2, None, True), (True, 4, 1.0, True)], out
+    from kdrt.ddp import BucketedAllReduce
+    from kdrt.optim import FlatParams
+    with pytest.raises(RuntimeError):                                # forcing needs a process group
+        BucketedAllReduce(FlatParams([torch.nn.Parameter(torch.zeros(4))]), ["w"], force=True)

@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 
 # measured on an MI355X (seeded random weights with non-trivial BatchNorm statistics): max |logit error| 0.55-0.98 % of the
 # logit range, argmax agreement 99.41-99.88 %; bf16 keeps 8 mantissa bits per stored activation through ~25 layers
-LOGIT_TOL_REL = 3e-2
-ARGMAX_MIN = 0.98
+LOGIT_TOL_REL = 1.5e-2
+ARGMAX_MIN = 0.99
 
 
 @pytest.mark.parametrize("fusion", ("concat", "minimal"))
@@ -34,7 +34,7 @@ def test_bf16_forward_against_fp32_and_oracle(fusion, shape):
     print(f"bf16 vs fp32 HIP [{fusion} {shape}]: max|dlogit| {err:.4f} = {err / rng:.2%} of range {rng:.2f}, argmax agreement {agree:.4%}")
     assert err <= LOGIT_TOL_REL * rng, (err, rng)
     assert agree >= ARGMAX_MIN, agree
-    if HW <= 64:                                     # the CPU oracle too (small case: seconds)
+    if True:                                         # the CPU oracle too, at both shapes (eval forward of 2 frames: < 1 s)
         with torch.no_grad():
             zo, _ = O.complete_model(images, pts, O.clone_state(st), fusion_type=fusion, grid=(G, G), training=False)
         err_o = (z16.cpu() - zo).abs().max().item()

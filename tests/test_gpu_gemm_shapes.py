@@ -44,7 +44,7 @@ def test_forward_prologues_and_stats(M, K, N):
         rows = ops.lib.kd_pwconv_stat_rows_for(M, K, N, pro, epi)        # rows the launch for this shape writes
         partial = torch.zeros(rows * 2 * N, device="cuda") if epi else None
         ops.pw_gemm(Ad, W.cuda(), C, M=M, K=K, N=N, pro=pro, pro_act=act, p=(sc.cuda(), sh.cuda(), None, None, None),
-                    bias=bias.cuda() if use_bias else None, epi=epi, partial=partial)
+                    bias=bias.cuda() if use_bias else None, epi=epi, partial=partial, partial_rows=rows)
         _close(C, want, ("fwd", pro, act, use_bias, epi))
         assert torch.all(C._base[:, N:] == 7.0) if C._base is not None else True
         if epi:
@@ -76,7 +76,7 @@ def test_dgrad_and_wgrad(M, K, N):
     part = torch.zeros(rows * 2 * K, device="cuda")
     Wt = ops.transpose(c(W))                                           # [K][N]
     ops.pw_gemm(c(G), Wt, gin, M=M, K=N, N=K, A2=c(Y), pro=2, pro_act=1, p=(c(al), c(be), c(ga), c(msc), c(msh)), epi=2,
-                X=c(X), esc=c(esc), esh=c(esh), emean=c(mean), einv=c(inv), epi_act=1, partial=part)
+                X=c(X), esc=c(esc), esh=c(esh), emean=c(mean), einv=c(inv), epi_act=1, partial=part, partial_rows=rows)
     _close(gin, dx, "dgrad")
     st = part.view(rows, 2, K).double().sum(0).cpu()
     xhat = (d(X) - d(mean)) * d(inv)
@@ -124,7 +124,8 @@ def test_streaming_dgrad_same_bits_as_tiled(M, K, N, epi, with_addend):
         gin = torch.full((M, K), float("nan"), device="cuda")
         part = torch.zeros(rows * 2 * K, device="cuda") if epi == 2 else None
         ops.pw_gemm(G, Wt, gin, M=M, K=N, N=K, A2=Y, pro=2, pro_act=2, p=(al, be, ga, msc, msh), addend=add if with_addend else None,
-                    epi=epi, X=X if epi == 2 else None, esc=esc, esh=esh, emean=mean, einv=inv, epi_act=2, partial=part)
+                    epi=epi, X=X if epi == 2 else None, esc=esc, esh=esh, emean=mean, einv=inv, epi_act=2, partial=part,
+                    partial_rows=rows)
         torch.cuda.synchronize()
         return gin, (part.view(rows, 2, K).double().sum(0) if epi == 2 else None), rows
 
@@ -164,10 +165,63 @@ def test_streaming_lidar_l2_dgrad_same_bits_as_tiled():
         G1 = torch.full((M, C1), float("nan"), device="cuda")
         part = torch.zeros(rows * 2 * C1, device="cuda")
         lib.call("kd_lidar_l2_dgrad", P(Y2), C2, P(rows_t), P(grid), P(share), P(al), P(be), P(ga), P(sc2), P(sh2), 1, P(Wt2), P(G1), C1,
-                 P(Y1), C1, P(sc1), P(sh1), P(mean1), P(inv1), 1, P(part), M, C2, C1, stream())
+                 P(Y1), C1, P(sc1), P(sh1), P(mean1), P(inv1), 1, P(part), rows, M, C2, C1, stream())
         torch.cuda.synchronize()
         return G1, part.view(rows, 2, C1).double().sum(0), rows
 
     (a0, s0, r0), (a1, s1, r1) = _both_forms(run_l2)
     assert r0 != r1 and torch.equal(a0, a1)
     assert (s0 - s1).abs().max().item() <= 1e-5 * max(a0.double().abs().sum(0).max().item(), 1.0)
+
+
+def test_statistics_slab_sized_for_the_other_kernel_form_is_refused():
+    """Round 2's systematic 3e-4 gradient error came from a launch that silently took the tiled kernel
+    after the caller had sized -- and later reduced -- its BatchNorm-statistics slab for the streaming form.  The C ABI
+    now carries the caller's row count: a slab sized for the OTHER form is an argument error, for the forward
+    statistics (epi 1), the data-gradient sums (epi 2) and the LiDAR table-form data gradient alike."""
+    from kdrt import ops
+    from kdrt.lib import KDError
+    from kdrt.ops import lib, P, stream
+    if ops.get_gemm_arithmetic() != "split":
+        pytest.skip("the two kernel forms exist in the split arithmetic only")
+    M, K, N = 4096 * 3, 64, 128
+    g = torch.Generator().manual_seed(5)
+    A, W = torch.randn(M, K, generator=g).cuda(), torch.randn(N, K, generator=g).cuda()
+    Cout = torch.empty(M, N, device="cuda")
+    prev = lib.kd_set_gemm_stream(2)
+    try:
+        r_stream = lib.kd_pwconv_stat_rows_for(M, K, N, 0, 1)
+        lib.kd_set_gemm_stream(0)
+        r_tiled = lib.kd_pwconv_stat_rows_for(M, K, N, 0, 1)
+        assert r_tiled == (M + 127) // 128 and r_stream != r_tiled
+        part = torch.zeros(max(r_stream, r_tiled) * 2 * N, device="cuda")
+        for mode, good, bad in ((0, r_tiled, r_stream), (2, r_stream, r_tiled)):
+            lib.kd_set_gemm_stream(mode)
+            ops.pw_gemm(A, W, Cout, M=M, K=K, N=N, epi=1, partial=part, partial_rows=good)          # the matching count runs
+            for wrong in (bad, good - 1, 0):
+                with pytest.raises(KDError, match="statistics slab"):
+                    ops.pw_gemm(A, W, Cout, M=M, K=K, N=N, epi=1, partial=part, partial_rows=wrong)
+        # data gradient through an activation (epi 2)
+        G, Y, X = (torch.randn(M, n, generator=g).cuda() for n in (N, N, K))
+        v = lambda n: torch.rand(n, generator=g).cuda() + 0.5
+        al, be, ga, msc, msh, esc, esh, mean, inv = v(N), v(N), v(N), v(N), v(N), v(K), v(K), v(K), v(K)
+        Wt = ops.transpose(W)
+        gin = torch.empty(M, K, device="cuda")
+        lib.kd_set_gemm_stream(2)
+        rs = lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2)
+        lib.kd_set_gemm_stream(0)
+        rt = lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2)
+        assert rs != rt
+        part2 = torch.zeros(max(rs, rt) * 2 * K, device="cuda")
+        kw = dict(M=M, K=N, N=K, A2=Y, pro=2, pro_act=1, p=(al, be, ga, msc, msh), epi=2, X=X, esc=esc, esh=esh, emean=mean,
+                  einv=inv, epi_act=1, partial=part2)
+        with pytest.raises(KDError, match="statistics slab"):
+            ops.pw_gemm(G, Wt, gin, partial_rows=rs, **kw)            # tiled launch, slab sized for the streaming form
+        ops.pw_gemm(G, Wt, gin, partial_rows=rt, **kw)
+        lib.kd_set_gemm_stream(2)
+        with pytest.raises(KDError, match="statistics slab"):
+            ops.pw_gemm(G, Wt, gin, partial_rows=rt, **kw)            # and the other way round
+        ops.pw_gemm(G, Wt, gin, partial_rows=rs, **kw)
+        torch.cuda.synchronize()
+    finally:
+        lib.kd_set_gemm_stream(prev)

@@ -20,11 +20,11 @@ for M in (8192, 16384, 16384 + 77):
     xhat = (d(X) - d(mean)) * d(inv)
     c = lambda t: t.cuda()
     gin = torch.empty(M, K, device="cuda")
-    rows = ops.lib.kd_pwconv_stat_rows(M)
+    rows = ops.lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2)
     part = torch.zeros(rows * 2 * K, device="cuda")
     Wt = ops.transpose(c(W))
     ops.pw_gemm(c(G), Wt, gin, M=M, K=N, N=K, A2=c(Y), pro=2, pro_act=0, p=(c(al), c(be), c(ga), None, None), epi=2,
-                X=c(X), esc=c(esc), esh=c(esh), emean=c(mean), einv=c(inv), epi_act=1, partial=part)
+                X=c(X), esc=c(esc), esh=c(esh), emean=c(mean), einv=c(inv), epi_act=1, partial=part, partial_rows=rows)
     st = part.view(rows, 2, K).double().sum(0).cpu()
     bnc = BNC(K, "cuda"); bnc.mean.copy_(c(mean)); bnc.invstd.copy_(c(inv))
     dgamma, dbeta, abg, _ = ops.bn_bwd_finalize(part, rows, K, M, torch.ones(K, device="cuda"), bnc, True)
