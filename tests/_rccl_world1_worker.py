@@ -58,7 +58,7 @@ def run(student_fusion, forced, graphed=False):
     names = [n for n, p in student.named_parameters() if p.requires_grad]
     red = BucketedAllReduce(opt.flat, names, n_buckets=3, force=True) if forced else None
     step = KDStep(student, teacher, opt, torch.tensor([0.4, 3.5]).cuda(), reducer=red)
-    orders, syncs, snaps = [], 0, []
+    orders, syncs, snaps, where = [], 0, [], set()
     if graphed:
         # warm-up steps run eagerly on batch(0) inside the constructor; the capture itself executes nothing
         g = GraphedKDStep(step, *batch(0), warmup=STEPS)
@@ -82,11 +82,13 @@ def run(student_fusion, forced, graphed=False):
             if red is not None:
                 red._launch = orig
             torch.cuda.set_sync_debug_mode("default")
-            syncs += sum("synchroniz" in str(x.message).lower() for x in w)
+            hits = [x for x in w if "synchroniz" in str(x.message).lower()]
+            syncs += len(hits)
+            where.update(f"{os.path.basename(x.filename)}:{x.lineno}" for x in hits)
         orders.append(launch_log)
         torch.cuda.synchronize()
         snaps.append(snapshot(student, opt))
-    return {"snaps": snaps, "orders": orders, "syncs": syncs, "collectives": red.collectives_issued if red is not None else 0}
+    return {"snaps": snaps, "orders": orders, "syncs": syncs, "sync_sites": sorted(where), "collectives": red.collectives_issued if red is not None else 0}
 
 
 def main():
@@ -104,6 +106,7 @@ def main():
             "bit_identical_steps": [same(a, b) for a, b in zip(plain["snaps"], forced["snaps"])],
             "orders": forced["orders"], "collectives": forced["collectives"],
             "host_syncs_plain": plain["syncs"], "host_syncs_forced": forced["syncs"],
+            "sync_sites_plain": plain["sync_sites"], "sync_sites_forced": forced["sync_sites"],
         }
     # hipGraph capture with the collectives inside
     try:

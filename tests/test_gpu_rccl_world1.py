@@ -45,7 +45,8 @@ def test_forced_reducer_steps_are_bit_identical_and_ordered(result, fusion):
     assert r["bit_identical_steps"] == [True, True, True], r         # parameters, gradients, Adam moments, BN buffers
     assert r["orders"] == [[2, 1, 0]] * 3, r["orders"]               # bucket launch order = backward completion order
     assert r["collectives"] == 9, r                                   # 3 buckets x 3 steps really went to RCCL
-    assert r["host_syncs_forced"] == r["host_syncs_plain"], r         # the reducer adds no host synchronisation
+    assert r["host_syncs_forced"] <= r["host_syncs_plain"], r         # the reducer adds no host synchronisation
+    assert set(r["sync_sites_forced"]) <= set(r["sync_sites_plain"]), r
 
 
 def test_step_with_collectives_replays_from_a_hipgraph(result):
