@@ -202,6 +202,18 @@ int kd_lidar_l2_wgrad(const float* Y2, int64_t ldy2, const int* rows, const floa
                       const float* al, const float* be, const float* ga, const float* sc2, const float* sh2, int act2,
                       const float* Y1, int64_t ldy1, const float* sc1, const float* sh1, int act1, float* dW,
                       int64_t M, int N2, int K1, void* ws, size_t ws_bytes, void* stream);
+/* The same backward in ONE kernel (csrc/kd_lidar_bwd.hip): G1 + BatchNorm-1 backward sums (== kd_lidar_l2_dgrad, bit for bit)
+ * and dW2 (== kd_lidar_l2_wgrad up to summation order) from one read and one bf16x3 split of Y2 and Y1 -- 31 GB instead of
+ * 52 GB of HBM traffic at 256 frames x 80 000 points.  Split arithmetic, N2 = K1 = 128 (kd_lidar_l2_bwd_supported); `partial`
+ * has kd_lidar_l2_bwd_stat_rows(M) rows (passed back as partial_rows and checked), ws >= kd_lidar_l2_bwd_ws_bytes. */
+int kd_lidar_l2_bwd_supported(int N2, int K1);
+int64_t kd_lidar_l2_bwd_stat_rows(int64_t M);
+size_t kd_lidar_l2_bwd_ws_bytes(int64_t M, int N2, int K1);
+int kd_lidar_l2_bwd(const float* Y2, int64_t ldy2, const int* rows, const float* grid, const float* share, const float* al,
+                    const float* be, const float* ga, const float* sc2, const float* sh2, int act2, const float* Wt,
+                    float* G1, int64_t ldg1, const float* Y1, int64_t ldy1, const float* sc1, const float* sh1,
+                    const float* mean1, const float* invstd1, int act1, float* partial, int64_t partial_rows, float* dW,
+                    int64_t M, int N2, int K1, void* ws, size_t ws_bytes, void* stream);
 int kd_lidar_gather_sorted(const float* pts, const int* perm, const int* row_of_point, const int* nvalid_dev,
                            float* out_pts, int* out_row, int64_t P, void* stream);
 /* row_sorted (optional, rows sorted by kd_lidar_sort_points, perm == NULL): grid rows holding more than 256 points are

@@ -920,6 +920,8 @@ int wgrad_launch(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
 
 }  // namespace
 
+int kd_gemm_split_mode() { return g_gemm_split.load(std::memory_order_relaxed); }
+
 extern "C" {
 
 // 0: v_mfma_f32_32x32x2_f32 (exact fp32 products); 1: bf16x6 split products on v_mfma_f32_32x32x16_bf16.

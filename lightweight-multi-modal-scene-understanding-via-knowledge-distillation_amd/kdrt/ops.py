@@ -254,6 +254,24 @@ def l2_dgrad(tables, out_op: Operand, Wt, gin, *, inp: Operand, al, be, ga, part
     _prof_end(t0, "pw_gemm", 2.0 * M * N * K, 4.0 * (M * N + 2 * M * K + M + N * K), None, M)
 
 
+def l2_bwd(tables, out_op: Operand, Wt, gin, dW, *, inp: Operand, al, be, ga, partial, partial_rows):
+    """Last point-MLP layer, training backward in ONE kernel (csrc/kd_lidar_bwd.hip): data gradient + BatchNorm-backward sums
+    + weight gradient from one read and one split of Y2 and Y1.  Two profile records so the per-family accounting of
+    bench.py stays comparable: the launch is booked as its data-gradient GEMM (all its bytes, both GEMMs' FLOPs)."""
+    rows_t, grid, share = tables
+    y = out_op.raw
+    M, N = y.shape
+    K = inp.C
+    nbytes = lib.kd_lidar_l2_bwd_ws_bytes(M, N, K)
+    ws = workspace(nbytes, y.device)
+    t0 = _prof_begin()
+    lib.call("kd_lidar_l2_bwd", P(y), ld(y), P(rows_t), P(grid), P(share), P(al), P(be), P(ga), P(out_op.sc), P(out_op.sh), out_op.act,
+             P(Wt), P(gin), ld(gin), P(inp.raw), ld(inp.raw), P(inp.sc), P(inp.sh), P(inp.bnc.mean), P(inp.bnc.invstd), inp.act,
+             P(partial), partial_rows, P(dW), M, N, K, P(ws), nbytes, stream())
+    # algorithmic traffic: Y2 in, Y1 in, G1 out (the epilogue's second look at Y1 is an L2 hit by construction)
+    _prof_end(t0, "pw_gemm", 2.0 * 2.0 * M * N * K, 4.0 * (M * N + 2 * M * K + M + 2 * N * K), None, M)
+
+
 def l2_wgrad(tables, out_op: Operand, dW, *, inp: Operand, al, be, ga):
     rows_t, grid, share = tables
     y = out_op.raw

@@ -298,7 +298,10 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
         inp = rec.inp
         N, K = C, inp.C
         dW, w_dir = gradsink.out_for(rec.w)
-        if tables:
+        fused = (tables and need_input_grad and addend is None and _LIDAR_FUSED_BWD and lib.kd_lidar_l2_bwd_supported(N, K))
+        if fused:
+            pass            # data gradient and weight gradient in one kernel, below
+        elif tables:
             ops.l2_wgrad(t, out_op, dW, inp=inp, al=al, be=be, ga=ga)
         elif inp.virt is not None:
             ops.l1_wgrad(t, y, dW, op=inp, al=al, be=be, ga=ga, msc=msc, msh=msh, mact=mact)
@@ -323,6 +326,12 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
                     ops.l1_dgrad(t, y, Wt, gin, op=inp, al=al, be=be, ga=ga, msc=msc, msh=msh, mact=mact, partial=part_in,
                                  partial_rows=rows_in)
                     g_in = ("G", gin, part_in, rows_in)
+            elif fused:
+                gin = torch.empty(M, K, device=dev, dtype=torch.float32)
+                rows_in = lib.kd_lidar_l2_bwd_stat_rows(M)
+                part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
+                ops.l2_bwd(t, out_op, Wt, gin, dW, inp=inp, al=al, be=be, ga=ga, partial=part_in, partial_rows=rows_in)
+                g_in = ("G", gin, part_in, rows_in)
             elif tables:
                 gin = torch.empty(M, K, device=dev, dtype=torch.float32)
                 rows_in = lib.kd_lidar_l2_dgrad_stat_rows(M, N, K)
@@ -845,6 +854,9 @@ _SCATTER_MODE = os.environ.get("KD_SCATTER", "sorted")
 _SCATTER_TABLES = os.environ.get("KD_SCATTER_TABLES", "1") != "0"
 # layer 0's gradient through moments of G0 accumulated in the layer-1 dgrad epilogue (default) or through the stored G0
 _L0_MOMENTS = os.environ.get("KD_L0_MOMENTS", "1") != "0"
+# one backward kernel per point-MLP layer (data + weight gradient from one read of the operands, csrc/kd_lidar_bwd.hip);
+# "0": the separate dgrad / wgrad GEMM launches of round 2 (A/B and tests)
+_LIDAR_FUSED_BWD = os.environ.get("KD_LIDAR_FUSED_BWD", "1") != "0"
 
 
 _sort_cache: dict = {}

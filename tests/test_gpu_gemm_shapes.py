@@ -225,3 +225,76 @@ def test_statistics_slab_sized_for_the_other_kernel_form_is_refused():
         torch.cuda.synchronize()
     finally:
         lib.kd_set_gemm_stream(prev)
+
+
+@pytest.mark.parametrize("M", [20, 4133, 256 * 32 * 2 + 77, 300000])
+def test_lidar_l2_fused_backward_against_the_two_kernels_and_fp64(M):
+    """kd_lidar_l2_bwd (csrc/kd_lidar_bwd.hip: data + weight gradient of the last point-MLP layer in one kernel, one read and
+    one split of Y2 / Y1): G1 has the bits of kd_lidar_l2_dgrad, the BatchNorm-backward sums and dW2 agree with
+    kd_lidar_l2_dgrad / kd_lidar_l2_wgrad up to summation order, and dW2 is within 2e-5 of a float64 evaluation."""
+    from kdrt import ops
+    from kdrt.ops import lib, P, stream
+    if ops.get_gemm_arithmetic() != "split":
+        assert not lib.kd_lidar_l2_bwd_supported(128, 128)
+        pytest.skip("the one-kernel backward exists in the split arithmetic only")
+    assert lib.kd_lidar_l2_bwd_supported(128, 128) and not lib.kd_lidar_l2_bwd_supported(64, 128)
+    g = torch.Generator().manual_seed(M)
+    c = lambda t: t.cuda()
+    C1 = C2 = 128
+    cells = max(4, M // 9)
+    Y2, Y1 = c(torch.randn(M, C2, generator=g)), c(torch.randn(M, C1, generator=g))
+    rows_t = torch.randint(-1, cells, (M,), generator=g, dtype=torch.int32).sort().values.cuda()
+    sc2, sh2 = c(torch.rand(C2, generator=g) + 0.5), c(torch.randn(C2, generator=g) * 0.2)
+    v2 = torch.clamp_min(Y2 * sc2 + sh2, 0)
+    grid = torch.zeros(cells, C2, device="cuda")
+    ok = rows_t >= 0
+    grid.index_reduce_(0, rows_t[ok].long(), v2[ok], "amax", include_self=True)
+    share = c(torch.randn(cells, C2, generator=g))
+    al, be, ga = (c(torch.randn(C2, generator=g) * 0.5) for _ in range(3))
+    W2 = c(torch.randn(C2, C1, generator=g) / C2 ** 0.5)
+    Wt2 = ops.transpose(W2)                                           # [C1][C2]
+    sc1, sh1, mean1, inv1 = (c(torch.rand(C1, generator=g) + 0.5) for _ in range(4))
+    sh1 = sh1 - 1.0                                                   # about half the pre-activations below zero
+
+    # the two kernels
+    rows_d = lib.kd_lidar_l2_dgrad_stat_rows(M, C2, C1)
+    G1a = torch.full((M, C1), float("nan"), device="cuda")
+    part_a = torch.zeros(rows_d * 2 * C1, device="cuda")
+    lib.call("kd_lidar_l2_dgrad", P(Y2), C2, P(rows_t), P(grid), P(share), P(al), P(be), P(ga), P(sc2), P(sh2), 1, P(Wt2), P(G1a), C1,
+             P(Y1), C1, P(sc1), P(sh1), P(mean1), P(inv1), 1, P(part_a), rows_d, M, C2, C1, stream())
+    dWa = torch.empty(C2, C1, device="cuda")
+    nb = lib.kd_pwconv_wgrad_ws_bytes(M, C2, C1)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    lib.call("kd_lidar_l2_wgrad", P(Y2), C2, P(rows_t), P(grid), P(share), P(al), P(be), P(ga), P(sc2), P(sh2), 1, P(Y1), C1, P(sc1),
+             P(sh1), 1, P(dWa), M, C2, C1, P(ws), nb, stream())
+    # one kernel
+    rows_f = lib.kd_lidar_l2_bwd_stat_rows(M)
+    G1b = torch.full((M + 3, C1), float("nan"), device="cuda")         # rows beyond M must stay untouched
+    part_b = torch.zeros(rows_f * 2 * C1, device="cuda")
+    dWb = torch.empty(C2, C1, device="cuda")
+    nb2 = lib.kd_lidar_l2_bwd_ws_bytes(M, C2, C1)
+    ws2 = torch.empty(nb2, dtype=torch.uint8, device="cuda")
+    args = (P(Y2), C2, P(rows_t), P(grid), P(share), P(al), P(be), P(ga), P(sc2), P(sh2), 1, P(Wt2), P(G1b), C1, P(Y1), C1, P(sc1), P(sh1),
+            P(mean1), P(inv1), 1, P(part_b))
+    lib.call("kd_lidar_l2_bwd", *args, rows_f, P(dWb), M, C2, C1, P(ws2), nb2, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(G1a, G1b[:M]) and bool(torch.isnan(G1b[M:]).all())
+    sa, sb = part_a.view(rows_d, 2, C1).double().sum(0), part_b.view(rows_f, 2, C1).double().sum(0)
+    assert (sa - sb).abs().max().item() <= 1e-5 * max(G1a.double().abs().sum(0).max().item(), 1.0)
+    # float64 reference of the weight gradient
+    d = lambda t: t.double()
+    v = torch.clamp_min(d(Y2) * d(sc2) + d(sh2), 0)
+    rl = rows_t.long().clamp_min(0)
+    Gs = torch.where(ok[:, None] & (v.float() > 0) & (v.float() == grid[rl]), d(share[rl]), torch.zeros((), dtype=torch.float64, device="cuda"))
+    dy = d(al) * Gs + d(be) * d(Y2) + d(ga)
+    a1 = torch.clamp_min(d(Y1) * d(sc1) + d(sh1), 0)
+    want = dy.t() @ a1
+    scale = want.abs().max().item()
+    assert (dWb.double() - want).abs().max().item() <= 2e-5 * scale, ((dWb.double() - want).abs().max().item(), scale)
+    assert (dWb - dWa).abs().max().item() <= 1e-5 * scale
+    # a slab sized for another launch is refused; so is an unsupported shape
+    from kdrt.lib import KDError
+    with pytest.raises(KDError, match="statistics slab"):
+        lib.call("kd_lidar_l2_bwd", *args, rows_f + 1, P(dWb), M, C2, C1, P(ws2), nb2, stream())
+    with pytest.raises(KDError, match="no instance"):
+        lib.call("kd_lidar_l2_bwd", *args, rows_f, P(dWb), M, C2, 64, P(ws2), nb2, stream())

@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r3b; mkdir -p $O
+step() { local name=$1 t=$2; shift 2; echo "=== $name" | tee -a $O/steps.log
+  timeout -k 10 $t "$@" > $O/$name.log 2>&1; local rc=$?; echo "rc=$rc" | tee -a $O/steps.log
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a $O/steps.log; exit 1; fi; }
+step rccl 600 python -m pytest tests/test_gpu_rccl_world1.py -q
+step fp64 900 python -m pytest tests/test_gpu_parity.py -q -k "fp64 or every_student"
+step rest 1000 python -m pytest tests/test_gpu_trainer.py tests/test_gpu_units.py tests/test_gpu_bf16.py -q
+tail -5 $O/*.log
