@@ -9,7 +9,8 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 _ROOT = os.path.dirname(_PKG)
-SO_PATH = os.path.join(_PKG, "csrc", "libkd_hip.so")
+# KD_HIP_LIB: a development build of the same library (instrumented kernels under tools/dbg/); never a different backend
+SO_PATH = os.environ.get("KD_HIP_LIB") or os.path.join(_PKG, "csrc", "libkd_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "kd_hip.h")
 
 

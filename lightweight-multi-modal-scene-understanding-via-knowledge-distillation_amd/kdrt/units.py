@@ -298,7 +298,8 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
         inp = rec.inp
         N, K = C, inp.C
         dW, w_dir = gradsink.out_for(rec.w)
-        fused = (tables and need_input_grad and addend is None and _LIDAR_FUSED_BWD and lib.kd_lidar_l2_bwd_supported(N, K))
+        fused = (tables and need_input_grad and addend is None and _LIDAR_FUSED_BWD and lib.kd_lidar_l2_bwd_supported(N, K)
+                 and ld(y) == N and ld(inp.raw) == K)               # (dense operands: the one-kernel form addresses rows by 128)
         if fused:
             pass            # data gradient and weight gradient in one kernel, below
         elif tables:
