@@ -74,8 +74,8 @@ if hasattr(lib._dll, "kd_lb_dbg_read"):          # instrumented build (KD_HIP_LI
     fused(); torch.cuda.synchronize()
     lib._dll.kd_lb_dbg_read(buf, 1)
     its = max(buf[8], 1)                        # iterations summed over role-A waves
-    names = ["B: dy convert + LDS store", "B: issue loads", "B: wgrad k-loop", "B: barrier", "A: dgrad k-loop", "A: epilogue", "A: a1 convert + loads", "A: barrier"]
+    names = ["V: rows fetch + epilogue", "V: convert + LDS stores", "V: issue loads", "V: barrier", "M: both k-loops", "M: stage stores", "-", "M: barrier"]
     print("per-iteration cycles (s_memtime, averaged over the waves of the role):")
     for i, n in enumerate(names):
         print(f"  {n:28s} {buf[i] / its:8.0f}")
-    print(f"  B total {sum(buf[0:4]) / its:.0f}   A total {sum(buf[4:8]) / its:.0f}")
+    print(f"  V total {sum(buf[0:4]) / its:.0f}   M total {sum(buf[4:8]) / its:.0f}")

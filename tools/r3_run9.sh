@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r3n; mkdir -p $O
+step() { local name=$1 t=$2; shift 2; echo "=== $name" | tee -a $O/steps.log
+  timeout -k 10 $t "$@" > $O/$name.log 2>&1; local rc=$?; echo "rc=$rc" | tee -a $O/steps.log
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a $O/steps.log; exit 1; fi; }
+step tests1 900 python -m pytest tests/test_gpu_gemm_shapes.py tests/test_gpu_lidar_segments.py tests/test_gpu_full_size.py tests/test_gpu_units.py -q -x
+step bench 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16-forward
+step tests2 1000 python -m pytest tests/test_gpu_parity.py tests/test_gpu_trainer.py tests/test_gpu_ddp_one_gpu.py -q -x
+tail -3 $O/tests1.log $O/tests2.log; tail -1 $O/bench.log | cut -c1-400
