@@ -214,6 +214,16 @@ int kd_lidar_l2_bwd(const float* Y2, int64_t ldy2, const int* rows, const float*
                     float* G1, int64_t ldg1, const float* Y1, int64_t ldy1, const float* sc1, const float* sh1,
                     const float* mean1, const float* invstd1, int act1, float* partial, int64_t partial_rows, float* dW,
                     int64_t M, int N2, int K1, void* ws, size_t ws_bytes, void* stream);
+/* Layer 1 in the same one-kernel form: dW1, the BatchNorm-0 backward sums of G0 = (dy1 . W1) * relu'(bn0(l0(point))) and the
+ * moments m1_out[4][K0] = sum_m G0 * point (== kd_lidar_l1_dgrad(G0 = NULL, m1_out) + kd_lidar_l1_wgrad with an unmasked G:
+ * dy1 = al*G + be*Y1 + ga).  Split arithmetic, N1 = 128, K0 = 64, ReLU; G and Y1 dense. */
+int kd_lidar_l1_bwd_supported(int N1, int K0);
+int64_t kd_lidar_l1_bwd_stat_rows(int64_t M);
+size_t kd_lidar_l1_bwd_ws_bytes(int64_t M, int N1, int K0);
+int kd_lidar_l1_bwd(const float* G, int64_t ldg, const float* Y1, int64_t ldy, const float* al, const float* be, const float* ga,
+                    const float* Wt, const float* pts, const float* w0, const float* b0, const float* sc0, const float* sh0,
+                    const float* mean0, const float* invstd0, int act0, float* partial, int64_t partial_rows, float* m1_out,
+                    float* dW, int64_t M, int N1, int K0, void* ws, size_t ws_bytes, void* stream);
 int kd_lidar_gather_sorted(const float* pts, const int* perm, const int* row_of_point, const int* nvalid_dev,
                            float* out_pts, int* out_row, int64_t P, void* stream);
 /* row_sorted (optional, rows sorted by kd_lidar_sort_points, perm == NULL): grid rows holding more than 256 points are

@@ -465,6 +465,330 @@ __global__ __launch_bounds__(512, 1) void lidar_l2_bwd_kernel(LbArgs g) {
   }
 }
 
+// =====================================================================================================================
+// Layer 1 (Conv1d 64 -> 128, lidar_encoder.py:29) in the same form.  Its input is layer 0's output, which never exists in HBM:
+// the vector waves recompute a0 = relu(bn0(l0(point))) from the 16-byte point (kd_l0_raw: the evaluation order every other
+// kernel uses).  dy1 = al*G1 + be*Y1 + ga (G1 already carries act1': the operand of kd_lidar_l1_dgrad / _wgrad with mact = none).
+//   G0[32,64]   = (dy1 . W1) * relu'(z0)          never stored: BatchNorm-0 backward sums + the moments sum_m G0 * point
+//   dW1[128,64] += dy1^T . a0
+// Matrix waves 0 / 1: one 32x32 block of (dy1 . W1) each (W1^T rows as bf16 planes in registers); 2 / 3: four 32x32 tiles
+// of dW1 each.  48 MFMAs per wave and chunk.  The a0 planes are [row][64 bf16] (128-byte rows), 16-byte chunks swizzled by
+// bit 2 ^= (row >> 1) & 1: four consecutive rows of a transposing read fall into four different bank quarters.
+constexpr int L1N = 128, L1K = 64;
+constexpr int L1PD = LBCH * L1N, L1PA = LBCH * L1K;          // bf16 per dy / a0 plane
+constexpr int L1BUF = 3 * L1PD + 3 * L1PA;                   // bf16 per buffer
+constexpr int L1SF = LBCH * L1K;                             // floats per stage tile
+constexpr size_t L1_LDS = (size_t)2 * L1BUF * 2 + (size_t)2 * L1SF * 4 + (size_t)2 * LBCH * 16;   // 72 KB planes + 16 KB stage + 1 KB points
+
+struct L1Args {
+  const float* G; const float* Y1;                         // dense [M,128]: masked gradient from layer 2's backward, raw layer-1 output
+  const float* al; const float* be; const float* ga;      // BatchNorm-1 backward coefficients
+  const float* pts;                                        // [M,4]
+  const float* w0; const float* b0;                        // layer 0: [64][4], [64]
+  const float* sc0; const float* sh0; const float* mean0; const float* inv0;
+  const float* Wt;                                         // [64][128]: W1 transposed
+  float* partial;                                          // out [grid][2][64]
+  float* wslab;                                            // out [grid][128][64]
+  float* m1slab;                                           // out [grid][4][64]
+  int M;
+};
+
+__device__ __forceinline__ int la_off(int row, int c) { return row * L1K + ((c ^ (((row >> 1) & 1) << 2)) << 3); }
+__device__ __forceinline__ bf16x8 la_tr_frag(const unsigned short* plane, int row0, int col0, int lane) {
+  const int grp = lane >> 4, li = lane & 15;
+  const int row = row0 + 8 * (grp >> 1) + (li >> 2);
+  const int col = col0 + 16 * (grp & 1) + 4 * (li & 3);
+  const unsigned short* p0 = plane + la_off(row, col >> 3) + (col & 7);
+  const unsigned short* p1 = plane + la_off(row + 4, col >> 3) + (col & 7);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(512, 1) void lidar_l1_bwd_kernel(L1Args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* lds = reinterpret_cast<unsigned short*>(smem_raw);                 // [2][3 dy planes | 3 a0 planes]
+  float* stage = reinterpret_cast<float*>(smem_raw + (size_t)2 * L1BUF * 2);         // [2][32][64]
+  float4* ldp = reinterpret_cast<float4*>(stage + 2 * L1SF);                         // [2][32] points of the chunk in each buffer
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int M = g.M;
+  const int nchunk = (M + LBCH - 1) / LBCH;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int nit = b < nchunk ? (nchunk - b + G - 1) / G : 0;
+  auto chunk_at = [&](int it) __attribute__((always_inline)) { return b + __builtin_amdgcn_readfirstlane(min(max(it, 0), nit - 1)) * G; };
+  auto last_at = [&](int it) __attribute__((always_inline)) {
+    const int vm = -(int)(it >= 0 && it < nit);
+    return ((M - 1 - chunk_at(it) * LBCH) & vm) | ~vm;
+  };
+  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+
+  if (wave < 4) {
+    // ======== vector waves
+    const int c4 = tid & 31, rb = tid >> 5;                               // dy layout: float4 column group, rows rb + 8 i (i < 4)
+    const int c4a = tid & 15, ra = tid >> 4;                              // a0 / epilogue layout: 4 of the 64 channels, rows ra + 16 i (i < 2)
+    int cvo[4], cao[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cvo[i] = lb_off(rb + 8 * i, c4 >> 1) + (c4 & 1) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) cao[i] = la_off(ra + 16 * i, c4a >> 1) + (c4a & 1) * 4;
+    const float4 cal = kd_ld4(g.al + 4 * c4), cbe = kd_ld4(g.be + 4 * c4), cga = kd_ld4(g.ga + 4 * c4);
+    float4 cw[4];                                                         // layer-0 weights of this thread's 4 channels
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cw[k] = kd_ld4(g.w0 + (4 * c4a + k) * 4);
+    const float4 cb = kd_ld4(g.b0 + 4 * c4a), cs = kd_ld4(g.sc0 + 4 * c4a), ch = kd_ld4(g.sh0 + 4 * c4a);
+    const float4 cmean = kd_ld4(g.mean0 + 4 * c4a), cinv = kd_ld4(g.inv0 + 4 * c4a);
+    float4 rg[2][4], ry[2][4], rp[2][2];
+    float4 s1 = kd_zero4(), s2 = kd_zero4(), m1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m1[k] = kd_zero4();
+    auto load_rows4 = [&](const float* T, int chunk, float4 (&dst)[4]) __attribute__((always_inline)) {
+      const float* base = T + (size_t)chunk * (LBCH * L1N);
+      const int last = M - 1 - chunk * LBCH;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = rb + 8 * i;
+        dst[i] = kd_ld4(base + (row < last ? row : last) * L1N + 4 * c4);
+      }
+    };
+    auto load_pts = [&](int chunk, float4 (&dst)[2]) __attribute__((always_inline)) {
+      const float* base = g.pts + (size_t)chunk * (LBCH * 4);
+      const int last = M - 1 - chunk * LBCH;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = ra + 16 * i;
+        dst[i] = kd_ld4(base + (row < last ? row : last) * 4);
+      }
+    };
+    auto convert_store = [&](int last, const float4 (&sg)[4], const float4 (&sy)[4], const float4 (&sp)[2], int bufi) __attribute__((always_inline)) {
+      unsigned short* buf = lds + bufi * L1BUF;
+      {
+        float4 vw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          vw[i].x = fmaf(cal.x, sg[i].x, fmaf(cbe.x, sy[i].x, cga.x));
+          vw[i].y = fmaf(cal.y, sg[i].y, fmaf(cbe.y, sy[i].y, cga.y));
+          vw[i].z = fmaf(cal.z, sg[i].z, fmaf(cbe.z, sy[i].z, cga.z));
+          vw[i].w = fmaf(cal.w, sg[i].w, fmaf(cbe.w, sy[i].w, cga.w));
+        }
+        uint2 hi[4], mid[4], lo[4];
+        lb_split3_lockstep<4>(vw, hi, mid, lo);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned short* d = buf + cvo[i];
+          *reinterpret_cast<uint2*>(d) = hi[i];
+          *reinterpret_cast<uint2*>(d + L1PD) = mid[i];
+          *reinterpret_cast<uint2*>(d + 2 * L1PD) = lo[i];
+        }
+      }
+      {
+        float4 vw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float4 x = kd_l0_raw4(sp[i], cw, cb);
+          vw[i] = make_float4(fmaxf(kd_affine(x.x, cs.x, ch.x), 0.f), fmaxf(kd_affine(x.y, cs.y, ch.y), 0.f),
+                              fmaxf(kd_affine(x.z, cs.z, ch.z), 0.f), fmaxf(kd_affine(x.w, cs.w, ch.w), 0.f));
+          if (c4a == 0) ldp[bufi * LBCH + ra + 16 * i] = sp[i];
+        }
+        uint2 hi[2], mid[2], lo[2];
+        lb_split3_lockstep<2>(vw, hi, mid, lo);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          unsigned short* d = buf + 3 * L1PD + cao[i];
+          *reinterpret_cast<uint2*>(d) = hi[i];
+          *reinterpret_cast<uint2*>(d + L1PA) = mid[i];
+          *reinterpret_cast<uint2*>(d + 2 * L1PA) = lo[i];
+        }
+      }
+      if (last < LBCH - 1) {                    // tail chunk / padding iteration: rows beyond M contribute nothing to dW1
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (rb + 8 * i > last) {
+            const uint2 z = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(buf + cvo[i]) = z;
+            *reinterpret_cast<uint2*>(buf + L1PD + cvo[i]) = z;
+            *reinterpret_cast<uint2*>(buf + 2 * L1PD + cvo[i]) = z;
+          }
+      }
+    };
+    // G0 of one chunk from the matrix waves' stage tile: mask, BatchNorm-0 backward sums, moments with the point
+    auto epilogue = [&](int it) __attribute__((always_inline)) {
+      const int last = last_at(it), bufi = it & 1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = ra + 16 * i;
+        const float4 d = kd_ld4(stage + bufi * L1SF + row * L1K + 4 * c4a);
+        const float4 pt = ldp[bufi * LBCH + row];
+        const bool ok = row <= last;
+        const float4 x = kd_l0_raw4(pt, cw, cb);
+        float4 v;
+        v.x = (ok && kd_affine(x.x, cs.x, ch.x) > 0.f) ? d.x : 0.f;
+        v.y = (ok && kd_affine(x.y, cs.y, ch.y) > 0.f) ? d.y : 0.f;
+        v.z = (ok && kd_affine(x.z, cs.z, ch.z) > 0.f) ? d.z : 0.f;
+        v.w = (ok && kd_affine(x.w, cs.w, ch.w) > 0.f) ? d.w : 0.f;
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x = fmaf(v.x, (x.x - cmean.x) * cinv.x, s2.x);
+        s2.y = fmaf(v.y, (x.y - cmean.y) * cinv.y, s2.y);
+        s2.z = fmaf(v.z, (x.z - cmean.z) * cinv.z, s2.z);
+        s2.w = fmaf(v.w, (x.w - cmean.w) * cinv.w, s2.w);
+        const float pj[4] = {pt.x, pt.y, pt.z, pt.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          m1[k].x = fmaf(v.x, pj[k], m1[k].x); m1[k].y = fmaf(v.y, pj[k], m1[k].y);
+          m1[k].z = fmaf(v.z, pj[k], m1[k].z); m1[k].w = fmaf(v.w, pj[k], m1[k].w);
+        }
+      }
+    };
+    auto step = [&](int it, auto set_tag) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_tag)::value;
+      epilogue(it - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      convert_store(last_at(it + 1), rg[S], ry[S], rp[S], (it + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int c3 = chunk_at(it + 3);
+      load_rows4(g.G, c3, rg[S]);
+      load_rows4(g.Y1, c3, ry[S]);
+      load_pts(c3, rp[S]);
+      __builtin_amdgcn_sched_barrier(0);
+      kd_lds_barrier();
+    };
+    for (int i = tid; i < (2 * L1SF + 2 * LBCH * 4) / 4; i += 256) kd_st4(stage + 4 * i, kd_zero4());     // stage + points: finite from the first read on
+    if (nit > 0) {
+      load_rows4(g.G, chunk_at(0), rg[0]); load_rows4(g.Y1, chunk_at(0), ry[0]); load_pts(chunk_at(0), rp[0]);
+      load_rows4(g.G, chunk_at(1), rg[1]); load_rows4(g.Y1, chunk_at(1), ry[1]); load_pts(chunk_at(1), rp[1]);
+    }
+    kd_lds_barrier();                                                     // (the zero fill above, before the first points land in ldp)
+    if (nit > 0) {
+      convert_store(last_at(0), rg[0], ry[0], rp[0], 0);
+      load_rows4(g.G, chunk_at(2), rg[0]); load_rows4(g.Y1, chunk_at(2), ry[0]); load_pts(chunk_at(2), rp[0]);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0): enter the loop with an empty queue (see layer 2)
+    kd_lds_barrier();
+    int it = 0;
+    for (; it < nit; it += 2) {
+      step(it, std::integral_constant<int, 1>{});
+      step(it + 1, std::integral_constant<int, 0>{});
+    }
+    if (nit > 0) epilogue(it - 1);
+    // column sums of the sixteen row groups -> one slab row per workgroup (fixed order)
+    kd_lds_barrier();
+    float* red = reinterpret_cast<float*>(smem_raw);                      // [16][6][64] floats over the (dead) planes
+    kd_st4(red + (ra * 6 + 0) * L1K + 4 * c4a, s1);
+    kd_st4(red + (ra * 6 + 1) * L1K + 4 * c4a, s2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) kd_st4(red + (ra * 6 + 2 + k) * L1K + 4 * c4a, m1[k]);
+    kd_lds_barrier();
+    for (int i = tid; i < 6 * L1K; i += 256) {
+      const int st = i / L1K, c = i % L1K;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[(k * 6 + st) * L1K + c];
+      if (st < 2) g.partial[(b * 2 + st) * L1K + c] = t;
+      else g.m1slab[(b * 4 + st - 2) * L1K + c] = t;
+    }
+  } else {
+    // ======== matrix waves
+    const int j = wave - 4;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (j < 2) {
+      // (dy1 . W1): one 32-column block
+      const int col = 32 * j + r;
+      bf16x8 Wb[8][3];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* wp = g.Wt + col * L1N + 16 * u + 8 * h;
+        uint2 h0, m0, l0, h1, m1, l1;
+        kd_split3(kd_ld4(wp), h0, m0, l0);
+        kd_split3(kd_ld4(wp + 4), h1, m1, l1);
+        const u32x4 vh = {h0.x, h0.y, h1.x, h1.y}, vm = {m0.x, m0.y, m1.x, m1.y}, vl = {l0.x, l0.y, l1.x, l1.y};
+        Wb[u][0] = __builtin_bit_cast(bf16x8, vh);
+        Wb[u][1] = __builtin_bit_cast(bf16x8, vm);
+        Wb[u][2] = __builtin_bit_cast(bf16x8, vl);
+      }
+      const int o_lane = 4 * h * L1K + col;
+      const int a_row = r * L1N, a_kk = (h ^ lb_key(r)) << 3;
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      kd_lds_barrier();
+      kd_lds_barrier();
+      const int nit2 = (nit + 1) & ~1;
+      for (int it = 0; it < nit2; ++it) {
+        const unsigned short* buf = lds + (it & 1) * L1BUF;
+        f32x16 dacc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dacc[q] = 0.f;
+        bf16x8 ap[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) ap[0][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(buf + a_row + a_kk + pl * L1PD));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (u < 7) {
+            const unsigned short* p = buf + a_row + (a_kk ^ (16 * (u + 1)));
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) ap[(u + 1) & 1][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + pl * L1PD));
+          }
+#pragma unroll
+          for (int t = 0; t < 6; ++t) dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[u & 1][PA[t]], Wb[u][PB[t]], dacc, 0, 0, 0);
+        }
+        float* sb = stage + (it & 1) * L1SF + o_lane;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sb[((q & 3) + 8 * (q >> 2)) * L1K] = dacc[q];
+        kd_lds_barrier();
+      }
+      kd_lds_barrier();
+      kd_lds_barrier();
+    } else {
+      // dW1: n blocks 2 (j - 2), 2 (j - 2) + 1, both k blocks
+      const int nb0 = 2 * (j - 2);
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[i][k][q] = 0.f;
+      kd_lds_barrier();
+      kd_lds_barrier();
+      const int nit2 = (nit + 1) & ~1;
+      for (int it = 0; it < nit2; ++it) {
+        const unsigned short* buf = lds + (it & 1) * L1BUF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            bf16x8 d[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) d[pl] = lb_tr_frag(buf + pl * L1PD, 16 * ks, 32 * (nb0 + ni), lane);
+#pragma unroll
+            for (int ki = 0; ki < 2; ++ki) {
+              bf16x8 a[3];
+#pragma unroll
+              for (int pl = 0; pl < 3; ++pl) a[pl] = la_tr_frag(buf + 3 * L1PD + pl * L1PA, 16 * ks, 32 * ki, lane);
+#pragma unroll
+              for (int t = 0; t < 6; ++t)
+                acc[ni][ki] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d[PA[t]], a[PB[t]], acc[ni][ki], 0, 0, 0);
+            }
+          }
+        kd_lds_barrier();
+      }
+      kd_lds_barrier();
+      kd_lds_barrier();
+      float* out = g.wslab + (size_t)b * (L1N * L1K);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) {
+          const int oc = 32 * ki + r;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int row = 32 * (nb0 + ni) + (q & 3) + 8 * (q >> 2) + 4 * h;
+            out[row * L1K + oc] = acc[ni][ki][q];
+          }
+        }
+    }
+  }
+}
+
 int lb_grid(int64_t M) {
   const int64_t nchunk = (M + LBCH - 1) / LBCH;
   return (int)(nchunk < 256 ? nchunk : 256);       // one workgroup per CU (96 KB of LDS, 8 waves)
@@ -517,6 +841,48 @@ int kd_lidar_l2_bwd(const float* Y2, int64_t ldy2, const int* rows, const float*
   const int rc = kd_check_launch("kd_lidar_l2_bwd");
   if (rc) return rc;
   return kd_slab_reduce_launch((const float*)ws, grid_x, (int64_t)N2 * K1, dW, st);
+}
+
+
+// ---- layer 1 ------------------------------------------------------------------------------------------------------
+int kd_lidar_l1_bwd_supported(int N1, int K0) { return kd_gemm_split_mode() && N1 == L1N && K0 == L1K; }
+int64_t kd_lidar_l1_bwd_stat_rows(int64_t M) { return lb_grid(M); }
+size_t kd_lidar_l1_bwd_ws_bytes(int64_t M, int N1, int K0) { return (size_t)lb_grid(M) * ((size_t)N1 * K0 + 4 * K0) * sizeof(float); }
+
+// Training backward of point-MLP layer 1 in ONE kernel: dW1, the BatchNorm-0 backward sums of G0 = (dy1 . W1) * relu'(.) and
+// the moments m1[j][c] = sum_m G0[m][c] * point[m][j] (kd_lidar_l1_dgrad with m1_out and G0 = NULL, + kd_lidar_l1_wgrad).
+// dy1 = al*G + be*Y1 + ga.  G and Y1 dense [M,128]; Wt = W1^T [64][128]; act0 must be ReLU.
+int kd_lidar_l1_bwd(const float* G, int64_t ldg, const float* Y1, int64_t ldy, const float* al, const float* be, const float* ga,
+                    const float* Wt, const float* pts, const float* w0, const float* b0, const float* sc0, const float* sh0,
+                    const float* mean0, const float* invstd0, int act0, float* partial, int64_t partial_rows, float* m1_out,
+                    float* dW, int64_t M, int N1, int K0, void* ws, size_t ws_bytes, void* stream) {
+  KD_REQUIRE(G && Y1 && al && be && ga && Wt && pts && w0 && b0 && sc0 && sh0 && mean0 && invstd0 && partial && m1_out && dW && ws && M > 0,
+             KD_ERR_ARG, "kd_lidar_l1_bwd: bad args");
+  KD_REQUIRE(kd_lidar_l1_bwd_supported(N1, K0), KD_ERR_SHAPE,
+             "kd_lidar_l1_bwd: no instance for N1=%d K0=%d in the %s arithmetic (use kd_lidar_l1_dgrad + kd_lidar_l1_wgrad)", N1, K0,
+             kd_gemm_split_mode() ? "split" : "exact-fp32");
+  KD_REQUIRE(M < (int64_t)1 << 31 && ldg == N1 && ldy == N1, KD_ERR_SHAPE, "kd_lidar_l1_bwd: G and Y1 must be dense [M,128] matrices");
+  KD_REQUIRE(act0 == KD_ACT_RELU, KD_ERR_ARG, "kd_lidar_l1_bwd: layer 0's activation must be ReLU (lidar_encoder.py:28)");
+  KD_REQUIRE(kd_aligned16(G) && kd_aligned16(Y1) && kd_aligned16(al) && kd_aligned16(be) && kd_aligned16(ga) && kd_aligned16(Wt) &&
+             kd_aligned16(pts) && kd_aligned16(w0) && kd_aligned16(b0) && kd_aligned16(sc0) && kd_aligned16(sh0) && kd_aligned16(mean0) &&
+             kd_aligned16(invstd0) && kd_aligned16(ws), KD_ERR_ALIGN, "kd_lidar_l1_bwd: 16-byte alignment");
+  const int grid_x = lb_grid(M);
+  KD_REQUIRE(partial_rows == grid_x, KD_ERR_ARG, "kd_lidar_l1_bwd: statistics slab sized for %lld rows, this launch writes %d "
+             "(kd_lidar_l1_bwd_stat_rows)", (long long)partial_rows, grid_x);
+  KD_REQUIRE(ws_bytes >= kd_lidar_l1_bwd_ws_bytes(M, N1, K0), KD_ERR_WORKSPACE, "kd_lidar_l1_bwd: workspace too small (%zu B)", ws_bytes);
+  static std::atomic<uint64_t> lds_raised{0};
+  const hipError_t e = kd_raise_dynamic_lds((const void*)lidar_l1_bwd_kernel, L1_LDS, lds_raised);
+  KD_REQUIRE(e == hipSuccess, (int)e, "kd_lidar_l1_bwd: cannot raise the dynamic LDS limit to %zu B: %s", L1_LDS, hipGetErrorString(e));
+  float* wslab = (float*)ws;
+  float* m1slab = wslab + (size_t)grid_x * N1 * K0;
+  L1Args g{G, Y1, al, be, ga, pts, w0, b0, sc0, sh0, mean0, invstd0, Wt, partial, wslab, m1slab, (int)M};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(lidar_l1_bwd_kernel, dim3(grid_x), dim3(512), L1_LDS, st, g);
+  int rc = kd_check_launch("kd_lidar_l1_bwd");
+  if (rc) return rc;
+  rc = kd_slab_reduce_launch(wslab, grid_x, (int64_t)N1 * K0, dW, st);
+  if (rc) return rc;
+  return kd_slab_reduce_launch(m1slab, grid_x, (int64_t)4 * K0, m1_out, st);
 }
 
 #ifdef KD_LB_DBG

@@ -240,6 +240,19 @@ def l1_dgrad(t, y, Wt, gin, *, op: Operand, al, be, ga, msc, msh, mact, partial,
     _prof_end(e0, "pw_gemm", 2.0 * M * N1 * K0, 4.0 * (2 * M * N1 + (M * K0 if gin is not None else 0) + M * 4 + N1 * K0), None, M)
 
 
+def l1_bwd(t, y, Wt, dW, *, op: Operand, al, be, ga, partial, partial_rows, moments):
+    """Point-MLP layer 1, training backward in ONE kernel (csrc/kd_lidar_bwd.hip): weight gradient + BatchNorm-0 backward sums
+    + the G0 * point moments from one read and one split of (G1, Y1); layer 0 recomputed from the points."""
+    pts, w0, b0 = op.virt
+    M, N1, K0 = pts.shape[0], y.shape[1], w0.shape[0]
+    nbytes = lib.kd_lidar_l1_bwd_ws_bytes(M, N1, K0)
+    ws = workspace(nbytes, y.device)
+    e0 = _prof_begin()
+    lib.call("kd_lidar_l1_bwd", P(t), ld(t), P(y), ld(y), P(al), P(be), P(ga), P(Wt), P(pts), P(w0), P(b0), P(op.sc), P(op.sh),
+             P(op.bnc.mean), P(op.bnc.invstd), op.act, P(partial), partial_rows, P(moments), P(dW), M, N1, K0, P(ws), nbytes, stream())
+    _prof_end(e0, "pw_gemm", 2.0 * 2.0 * M * N1 * K0, 4.0 * (2 * M * N1 + M * 4 + 2 * N1 * K0), None, M)
+
+
 def l2_dgrad(tables, out_op: Operand, Wt, gin, *, inp: Operand, al, be, ga, partial, partial_rows):
     """Data gradient of the last point-MLP layer with the scatter-max gradient rebuilt from (row_sorted, grid, share)."""
     rows_t, grid, share = tables

@@ -300,7 +300,9 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
         dW, w_dir = gradsink.out_for(rec.w)
         fused = (tables and need_input_grad and addend is None and _LIDAR_FUSED_BWD and lib.kd_lidar_l2_bwd_supported(N, K)
                  and ld(y) == N and ld(inp.raw) == K)               # (dense operands: the one-kernel form addresses rows by 128)
-        if fused:
+        fused1 = (inp.virt is not None and need_input_grad and addend is None and _LIDAR_FUSED_BWD and _L0_MOMENTS and not tables
+                  and mact == ACT_NONE and inp.act == ACT_RELU and lib.kd_lidar_l1_bwd_supported(N, K) and ld(t) == N and ld(y) == N)
+        if fused or fused1:
             pass            # data gradient and weight gradient in one kernel, below
         elif tables:
             ops.l2_wgrad(t, out_op, dW, inp=inp, al=al, be=be, ga=ga)
@@ -311,7 +313,13 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
                          a_mode=1 if inp.bnc is not None else 0, a_act=inp.act, asc=inp.sc, ash=inp.sh)
         if need_input_grad:
             Wt = ops.transpose(rec.w.view(N, K))
-            if inp.virt is not None:
+            if fused1:
+                rows_in = lib.kd_lidar_l1_bwd_stat_rows(M)
+                part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
+                m1 = torch.empty(4, K, device=dev, dtype=torch.float32)
+                ops.l1_bwd(t, y, Wt, dW, op=inp, al=al, be=be, ga=ga, partial=part_in, partial_rows=rows_in, moments=m1)
+                g_in = ("GM", m1, part_in, rows_in)
+            elif inp.virt is not None:
                 if addend is not None:
                     raise KDError("addend on a virtual LiDAR layer-0 input is not supported")
                 rows_in = lib.kd_lidar_l1_dgrad_stat_rows(M, N, K)

@@ -298,3 +298,71 @@ def test_lidar_l2_fused_backward_against_the_two_kernels_and_fp64(M):
         lib.call("kd_lidar_l2_bwd", *args, rows_f + 1, P(dWb), M, C2, C1, P(ws2), nb2, stream())
     with pytest.raises(KDError, match="no instance"):
         lib.call("kd_lidar_l2_bwd", *args, rows_f, P(dWb), M, C2, 64, P(ws2), nb2, stream())
+
+
+@pytest.mark.parametrize("M", [20, 4133, 256 * 32 * 2 + 77, 300000])
+def test_lidar_l1_fused_backward_against_the_two_kernels_and_fp64(M):
+    """kd_lidar_l1_bwd (csrc/kd_lidar_bwd.hip: layer 1's weight gradient, BatchNorm-0 backward sums and the G0 * point moments in
+    one kernel, layer 0 recomputed from the points) against kd_lidar_l1_dgrad(G0 = NULL, moments) + kd_lidar_l1_wgrad and
+    against a float64 evaluation."""
+    from kdrt import ops
+    from kdrt.ops import lib, P, stream
+    if ops.get_gemm_arithmetic() != "split":
+        assert not lib.kd_lidar_l1_bwd_supported(128, 64)
+        pytest.skip("the one-kernel backward exists in the split arithmetic only")
+    assert lib.kd_lidar_l1_bwd_supported(128, 64) and not lib.kd_lidar_l1_bwd_supported(128, 128)
+    g = torch.Generator().manual_seed(M + 1)
+    c = lambda t: t.cuda()
+    N1, K0 = 128, 64
+    G1, Y1 = c(torch.randn(M, N1, generator=g)), c(torch.randn(M, N1, generator=g))
+    pts = c(torch.randn(M, 4, generator=g) * torch.tensor([20.0, 20.0, 2.0, 0.3]))
+    w0, b0 = c(torch.randn(K0, 4, generator=g) * 0.1), c(torch.randn(K0, generator=g) * 0.1)
+    al, be, ga = (c(torch.randn(N1, generator=g) * 0.5) for _ in range(3))
+    W1 = c(torch.randn(N1, K0, generator=g) / N1 ** 0.5)
+    Wt1 = ops.transpose(W1)                                           # [K0][N1]
+    sc0, sh0, mean0, inv0 = c(torch.rand(K0, generator=g) + 0.5), c(torch.randn(K0, generator=g) * 0.3), c(torch.randn(K0, generator=g) * 0.1), c(torch.rand(K0, generator=g) + 0.5)
+
+    # the two kernels (moments form: G0 is not stored)
+    rows_d = lib.kd_lidar_l1_dgrad_stat_rows(M, N1, K0)
+    part_a = torch.zeros(rows_d * 2 * K0, device="cuda")
+    m1a = torch.empty(4, K0, device="cuda")
+    nbm = lib.kd_lidar_l1_dgrad_ws_bytes(M, K0)
+    wsm = torch.empty(nbm, dtype=torch.uint8, device="cuda")
+    lib.call("kd_lidar_l1_dgrad", P(G1), N1, P(Y1), N1, P(al), P(be), P(ga), None, None, 0, P(Wt1), None, K0, P(pts), P(w0), P(b0),
+             P(sc0), P(sh0), P(mean0), P(inv0), 1, P(part_a), rows_d, P(m1a), P(wsm), nbm, M, N1, K0, stream())
+    dWa = torch.empty(N1, K0, device="cuda")
+    nb = lib.kd_pwconv_wgrad_ws_bytes(M, N1, K0)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    lib.call("kd_lidar_l1_wgrad", P(G1), N1, P(Y1), N1, 0, P(al), P(be), P(ga), None, None, P(pts), P(w0), P(b0), P(sc0), P(sh0), 1,
+             P(dWa), M, N1, K0, P(ws), nb, stream())
+    # one kernel
+    rows_f = lib.kd_lidar_l1_bwd_stat_rows(M)
+    part_b = torch.zeros(rows_f * 2 * K0, device="cuda")
+    m1b = torch.empty(4, K0, device="cuda")
+    dWb = torch.empty(N1, K0, device="cuda")
+    nb2 = lib.kd_lidar_l1_bwd_ws_bytes(M, N1, K0)
+    ws2 = torch.empty(nb2, dtype=torch.uint8, device="cuda")
+    args = (P(G1), N1, P(Y1), N1, P(al), P(be), P(ga), P(Wt1), P(pts), P(w0), P(b0), P(sc0), P(sh0), P(mean0), P(inv0), 1, P(part_b))
+    lib.call("kd_lidar_l1_bwd", *args, rows_f, P(m1b), P(dWb), M, N1, K0, P(ws2), nb2, stream())
+    torch.cuda.synchronize()
+    # float64 reference
+    d = lambda t: t.double()
+    dy = d(al) * d(G1) + d(be) * d(Y1) + d(ga)
+    x0 = d(pts) @ d(w0).t() + d(b0)
+    z0 = x0 * d(sc0) + d(sh0)
+    a0 = torch.clamp_min(z0, 0)
+    G0 = (dy @ d(W1)) * (z0 > 0)
+    want_dW = dy.t() @ a0
+    want_s = torch.stack([G0.sum(0), (G0 * (x0 - d(mean0)) * d(inv0)).sum(0)])
+    want_m1 = d(pts).t() @ G0
+    sa, sb = part_a.view(rows_d, 2, K0).double().sum(0), part_b.view(rows_f, 2, K0).double().sum(0)
+    tol = lambda ref: 2e-5 * max(ref.abs().max().item(), 1e-6) * max(1.0, (M / 4096) ** 0.5)
+    assert (sb - want_s).abs().max().item() <= tol(want_s), ((sb - want_s).abs().max().item(), want_s.abs().max().item())
+    assert (sb - sa).abs().max().item() <= tol(want_s)
+    assert (m1b.double() - want_m1).abs().max().item() <= tol(want_m1)
+    assert (m1b - m1a).abs().max().item() <= tol(want_m1)
+    assert (dWb.double() - want_dW).abs().max().item() <= 2e-5 * want_dW.abs().max().item()
+    assert (dWb - dWa).abs().max().item() <= 1e-5 * want_dW.abs().max().item()
+    from kdrt.lib import KDError
+    with pytest.raises(KDError, match="statistics slab"):
+        lib.call("kd_lidar_l1_bwd", *args, rows_f + 1, P(m1b), P(dWb), M, N1, K0, P(ws2), nb2, stream())
