@@ -433,6 +433,7 @@ def main():
             q[0] += flops; q[1] += nbytes; q[2] += secs; q[3] += max(flops / pipe_peak, nbytes / (HBM_PEAK_GBPS * 1e9)); q[4] += 1
         g = agg.get("pw_gemm", [0, 0, 1e-9, 0])
         w = agg.get("pw_wgrad", [0, 0, 1e-9, 0])
+        lb = agg.get("lidar_bwd", None)
         # The family is HBM-bound since its products moved to the bf16 matrix pipe (bf16x6 split arithmetic): the
         # roofline is algorithmic bytes / launch time against the HBM peak.  The matrix-pipe view is kept beside it:
         # fp32-equivalent FLOP/s (2MKN) and the bf16 FLOP/s actually executed (6 piece products per product).
@@ -441,7 +442,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
-            "kernel": "pw_stream_kernel<KB,NB,PRO,EPI> / pw_gemm_kernel<PRO,EPI> (1x1-conv fwd + dgrad, weight-resident streaming form where the shape allows, tiled form otherwise; " +
+            "kernel": "pw_stream_kernel<KB,NB,PRO,EPI> / pw_gemm_kernel<PRO,EPI> (1x1-conv fwd + dgrad incl. the point-MLP forward layers, weight-resident streaming form where the shape allows, tiled form otherwise; " +
                       ("bf16x6 split products on v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if arith == "split"
                        else "v_mfma_f32_32x32x2_f32)"),
             "launches_per_step": g[3] // 2, "avg_launch_us": round(1e6 * g[2] / max(g[3], 1), 2),
@@ -460,6 +461,17 @@ def main():
             "wgrad": {"achieved": round(w[1] / w[2] / 1e9, 1), "unit": "GB/s", "fp32_tflops": round(w[0] / w[2] / 1e12, 2),
                       "launches_per_step": w[3] // 2, "time_share_of_step": round(w[2] / 2 / (elapsed / args.steps), 3)},
         }
+        if lb is not None:
+            # the one-kernel LiDAR layer backwards (kd_lidar_l2_bwd / kd_lidar_l1_bwd: data + weight gradient of a point-MLP layer
+            # from one read of its operands): bound by the matrix pipe (12 bf16 MFMA products per fp32 multiply-add pair) and the
+            # conversion VALU beside it, not by HBM -- reported against the pipe, with their (already minimal) HBM rate beside it
+            out["roofline"]["lidar_layer_backward"] = {
+                "kernel": "lidar_l2_bwd_kernel / lidar_l1_bwd_kernel (csrc/kd_lidar_bwd.hip)", "bound": "mfma",
+                "launches_per_step": lb[3] // 2, "ms_per_step": round(lb[2] / 2 * 1e3, 2),
+                "executed_bf16_tflops": round(6 * lb[0] / lb[2] / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                "frac": round(6 * lb[0] / lb[2] / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                "fp32_equivalent_tflops": round(lb[0] / lb[2] / 1e12, 1), "hbm_GBps_of_its_minimal_traffic": round(lb[1] / lb[2] / 1e9, 0),
+                "replaces": "kd_lidar_l2_dgrad + _l2_wgrad + _l1_dgrad + _l1_wgrad: 21.8 ms and 94 GB of operand passes per step in round 2"}
         # HBM bytes per launch come from PMC counters, which need their own rocprofv3 passes: use the committed
         # measurement of this exact workload (profiles/), null for any other configuration
         for fn in ("r02_bench_pmc_traffic_B256.json", "r01_bench_pmc_traffic_B256.json"):

@@ -157,6 +157,14 @@ int kd_lidar_l0_bwd(const float* D, const float* Y, const float* w, const float*
 int kd_lidar_l2_fwd_scatter(const float* A, int64_t lda, const float* sc1, const float* sh1, int act1, const float* W2,
                             const float* bias2, const float* sc2, const float* sh2, int act2, const int* cell_idx,
                             float* grid, int64_t ncells, int64_t M, int K, int N, const int* m_dev, void* stream);
+/* The WHOLE eval-mode encoder in one kernel (csrc/kd_lidar_infer.hip): point MLP 4 -> 64 -> 128 -> 128 (Conv1d + eval BatchNorm +
+ * ReLU each, lidar_encoder.py:25-35) + scatter-max (:85-96); no activation leaves the CU (layer 1 is computed transposed so
+ * that its accumulators are layer 2's operand fragments).  Split arithmetic; zeroes `grid`; sc / sh = kd_bn_eval_coeffs. */
+int kd_lidar_mlp_scatter_infer_supported(int C0, int C1, int C2);
+int kd_lidar_mlp_scatter_infer(const float* pts, const int* cell, const int* p_dev, const float* w0, const float* b0,
+                               const float* sc0, const float* sh0, const float* W1, const float* bias1, const float* sc1,
+                               const float* sh1, const float* W2, const float* bias2, const float* sc2, const float* sh2,
+                               float* grid, int64_t ncells, int64_t P, int C0, int C1, int C2, void* stream);
 int kd_lidar_scatter_max_fwd(const float* pts, const float* y, const float* sc, const float* sh, int act,
                              float* grid, int B, int64_t N, int C, int H, int W, float x0, float x1, float y0,
                              float y1, void* stream);

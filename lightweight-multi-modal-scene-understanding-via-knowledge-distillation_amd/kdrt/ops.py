@@ -225,6 +225,19 @@ def l2_fwd_scatter(op: Operand, W, bias, bnc2: BNC, act2, cell_idx, grid, ncells
     _prof_end(e0, "pw_gemm", 2.0 * M * N * K, 4.0 * (M * K + M * 1 + N * K), m_dev, M)     # reads A + cell index; no output tensor
 
 
+def lidar_mlp_scatter_infer(pts, cell_idx, m_dev, l0, l1, l2, coeffs, grid, ncells):
+    """Eval: the whole point MLP + BEV scatter-max in one kernel (csrc/kd_lidar_infer.hip).  l0 / l1 / l2: the conv modules,
+    coeffs: their eval BNC triples."""
+    b0, b1, b2 = coeffs
+    Pn, C0, C1, C2 = pts.shape[0], l0.weight.shape[0], l1.weight.shape[0], l2.weight.shape[0]
+    e0 = _prof_begin()
+    lib.call("kd_lidar_mlp_scatter_infer", P(pts), P(cell_idx), P(m_dev), P(l0.weight), P(l0.bias), P(b0.scale), P(b0.shift),
+             P(l1.weight), P(l1.bias), P(b1.scale), P(b1.shift), P(l2.weight), P(l2.bias), P(b2.scale), P(b2.shift), P(grid), ncells,
+             Pn, C0, C1, C2, stream())
+    # both GEMMs of the launch; algorithmic traffic: the 16-byte point + its cell index in, nothing out but the scatter
+    _prof_end(e0, "lidar_infer", 2.0 * Pn * (C0 * C1 + C1 * C2), 4.0 * (Pn * 5 + C0 * C1 + C1 * C2), m_dev, Pn)
+
+
 def l1_dgrad(t, y, Wt, gin, *, op: Operand, al, be, ga, msc, msh, mact, partial, partial_rows, moments=None):
     """moments ([4, K0] tensor, optional): receives sum_m G0 * point; with it `gin` may be None (G0 is never written)."""
     pts, w0, b0 = op.virt
@@ -250,7 +263,7 @@ def l1_bwd(t, y, Wt, dW, *, op: Operand, al, be, ga, partial, partial_rows, mome
     e0 = _prof_begin()
     lib.call("kd_lidar_l1_bwd", P(t), ld(t), P(y), ld(y), P(al), P(be), P(ga), P(Wt), P(pts), P(w0), P(b0), P(op.sc), P(op.sh),
              P(op.bnc.mean), P(op.bnc.invstd), op.act, P(partial), partial_rows, P(moments), P(dW), M, N1, K0, P(ws), nbytes, stream())
-    _prof_end(e0, "pw_gemm", 2.0 * 2.0 * M * N1 * K0, 4.0 * (2 * M * N1 + M * 4 + 2 * N1 * K0), None, M)
+    _prof_end(e0, "lidar_bwd", 2.0 * 2.0 * M * N1 * K0, 4.0 * (2 * M * N1 + M * 4 + 2 * N1 * K0), None, M)
 
 
 def l2_dgrad(tables, out_op: Operand, Wt, gin, *, inp: Operand, al, be, ga, partial, partial_rows):
@@ -269,8 +282,7 @@ def l2_dgrad(tables, out_op: Operand, Wt, gin, *, inp: Operand, al, be, ga, part
 
 def l2_bwd(tables, out_op: Operand, Wt, gin, dW, *, inp: Operand, al, be, ga, partial, partial_rows):
     """Last point-MLP layer, training backward in ONE kernel (csrc/kd_lidar_bwd.hip): data gradient + BatchNorm-backward sums
-    + weight gradient from one read and one split of Y2 and Y1.  Two profile records so the per-family accounting of
-    bench.py stays comparable: the launch is booked as its data-gradient GEMM (all its bytes, both GEMMs' FLOPs)."""
+    + weight gradient from one read and one split of Y2 and Y1."""
     rows_t, grid, share = tables
     y = out_op.raw
     M, N = y.shape
@@ -281,8 +293,9 @@ def l2_bwd(tables, out_op: Operand, Wt, gin, dW, *, inp: Operand, al, be, ga, pa
     lib.call("kd_lidar_l2_bwd", P(y), ld(y), P(rows_t), P(grid), P(share), P(al), P(be), P(ga), P(out_op.sc), P(out_op.sh), out_op.act,
              P(Wt), P(gin), ld(gin), P(inp.raw), ld(inp.raw), P(inp.sc), P(inp.sh), P(inp.bnc.mean), P(inp.bnc.invstd), inp.act,
              P(partial), partial_rows, P(dW), M, N, K, P(ws), nbytes, stream())
-    # algorithmic traffic: Y2 in, Y1 in, G1 out (the epilogue's second look at Y1 is an L2 hit by construction)
-    _prof_end(t0, "pw_gemm", 2.0 * 2.0 * M * N * K, 4.0 * (M * N + 2 * M * K + M + 2 * N * K), None, M)
+    # algorithmic traffic of THIS launch: Y2 in, Y1 in, G1 out (each once); both GEMMs' FLOPs.  Its own record kind: the launch is
+    # bound by the matrix pipe + conversion VALU, not by HBM, and must not blur the roofline of the 1x1-conv GEMM family
+    _prof_end(t0, "lidar_bwd", 2.0 * 2.0 * M * N * K, 4.0 * (M * N + 2 * M * K + M + 2 * N * K), None, M)
 
 
 def l2_wgrad(tables, out_op: Operand, dW, *, inp: Operand, al, be, ga):

@@ -866,6 +866,8 @@ _L0_MOMENTS = os.environ.get("KD_L0_MOMENTS", "1") != "0"
 # one backward kernel per point-MLP layer (data + weight gradient from one read of the operands, csrc/kd_lidar_bwd.hip);
 # "0": the separate dgrad / wgrad GEMM launches of round 2 (A/B and tests)
 _LIDAR_FUSED_BWD = os.environ.get("KD_LIDAR_FUSED_BWD", "1") != "0"
+# the whole eval-mode encoder (point MLP + scatter-max) in one kernel (csrc/kd_lidar_infer.hip); "0": layer by layer
+_LIDAR_FUSED_INFER = os.environ.get("KD_LIDAR_FUSED_INFER", "1") != "0"
 
 
 _sort_cache: dict = {}
@@ -972,6 +974,13 @@ class LidarFn(torch.autograd.Function):
             last = units[-1]
             C = last.conv.weight.shape[0]
             grid = torch.empty(B * H * W, C, device=dev, dtype=torch.float32)
+            if (_LIDAR_FUSED_INFER and len(units) == 3 and [u.kind for u in units] == ["l0", "pw", "pw"]
+                    and all(u.act == ACT_RELU and u.has_bias for u in units)
+                    and lib.kd_lidar_mlp_scatter_infer_supported(*(u.conv.weight.shape[0] for u in units))):
+                # the whole eval encoder in one kernel: no activation leaves the CU
+                co = [_coeffs(u, None, 0, u.conv.weight.shape[0], 0, False, None, dev) for u in units]
+                ops.lidar_mlp_scatter_infer(cpts, ccell, counter, units[0].conv, units[1].conv, units[2].conv, co, grid, B * H * W)
+                return ops.nchw_from_matrix(grid, (B, H, W))
             cur = cpts
             for u in units[:-1]:
                 cur, _ = unit_forward(u, cur, False, m_dev=counter, virtual=(u.kind == "l0"))

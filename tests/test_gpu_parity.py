@@ -276,10 +276,14 @@ def test_kd_losses_and_logits_vs_oracle_for_every_student(student):
 
 
 @pytest.mark.parametrize("fusion", ("concat", "minimal", "weighted"))
-def test_inference_epilogue_same_bits_as_two_pass_eval(fusion):
+def test_inference_epilogue_same_bits_as_two_pass_eval(fusion, monkeypatch):
     """Under no_grad the tail of every eval-mode chain (1x1 conv + BatchNorm + activation + residual) runs inside the GEMM
-    epilogue; with autograd on, the same model takes the raw-GEMM + apply path.  Same bits, logits and intermediates."""
+    epilogue; with autograd on, the same model takes the raw-GEMM + apply path.  Same bits, logits and intermediates.
+    (The one-kernel eval LiDAR encoder is switched off here: it sums each k-step's sixteen products in another slot order
+    than the layer-by-layer kernels -- its own test below bounds that difference.)"""
     from _gpu_util import build_product, load_random_state
+    from kdrt import units
+    monkeypatch.setattr(units, "_LIDAR_FUSED_INFER", False)
     G = 16
     images, pts, _ = O.make_inputs(2, 64, 700, G, 5, pad_tail=60)
     images, pts = images.cuda(), pts.cuda()
@@ -293,3 +297,30 @@ def test_inference_epilogue_same_bits_as_two_pass_eval(fusion):
     assert m1.keys() == m2.keys()
     for k in m1:
         assert torch.equal(m1[k].view(torch.int32), m2[k].detach().view(torch.int32)), k
+
+
+@pytest.mark.parametrize("shape", ((2, 700, 16), (3, 20000, 64)))
+def test_one_kernel_eval_lidar_encoder_against_layer_by_layer(shape, monkeypatch):
+    """kd_lidar_mlp_scatter_infer (csrc/kd_lidar_infer.hip: point MLP 4 -> 64 -> 128 -> 128 + scatter-max, no activation leaves
+    the CU, layer 1 computed transposed) against the layer-by-layer inference path and the CPU oracle.  Layer 2 adds the same
+    products in a different slot order inside each MFMA: agreement to fp32 rounding, not bit for bit."""
+    from kdrt import ops, units
+    from src.models.lidar_encoder import LiDAREncoder
+    B, N, G = shape
+    _, pts, _ = O.make_inputs(B, 64, N, G, 9, pad_tail=N // 10)
+    enc = LiDAREncoder(encoder_type="spatial", grid_size=(G, G)).cuda()
+    st = O.randomize_state({k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}, 33)
+    enc.load_state_dict(st)
+    enc.eval()
+    with torch.no_grad():
+        fused = enc(pts.cuda())
+        monkeypatch.setattr(units, "_LIDAR_FUSED_INFER", False)
+        layered = enc(pts.cuda())
+    if ops.get_gemm_arithmetic() != "split":
+        assert torch.equal(fused, layered)          # (no one-kernel instance in the exact-fp32 arithmetic: the same path twice)
+        return
+    scale = layered.abs().max().item()
+    assert (fused - layered).abs().max().item() <= 2e-6 * scale, ((fused - layered).abs().max().item(), scale)
+    assert torch.equal(fused == 0, layered == 0)                     # empty cells stay exactly zero
+    want = O.spatial_lidar_encoder(pts, {k: v for k, v in st.items()}, "encoder.", (G, G), False)
+    assert max_err(fused, want)[0] < ftol(want)

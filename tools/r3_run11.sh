@@ -1,0 +1,11 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r3r; mkdir -p $O
+step() { local name=$1 t=$2; shift 2; echo "=== $name" | tee -a $O/steps.log
+  timeout -k 10 $t "$@" > $O/$name.log 2>&1; local rc=$?; echo "rc=$rc" | tee -a $O/steps.log
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a $O/steps.log; exit 1; fi; }
+step unit 300 python -m pytest tests/test_gpu_parity.py -q -x -k "one_kernel_eval_lidar"
+grep -q "passed" $O/unit.log || { tail -40 $O/unit.log; exit 1; }
+step parity 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_lidar_iterative_flag.py tests/test_gpu_eval_cache.py tests/test_gpu_bf16.py -q -x -k "not fp64"
+step bench 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16-forward
+for f in unit parity; do tail -n 3 $O/$f.log; done; tail -n 1 $O/bench.log | cut -c1-300
