@@ -53,8 +53,8 @@ const char* kd_last_error_string(void);
  * (error <= 2^-23 |x||y| per product, i.e. fp32-grade).  Process-wide; returns the previous setting. */
 int kd_set_gemm_split(int on);
 int64_t kd_pwconv_stat_rows(int64_t M);
-int64_t kd_pwconv_stat_rows_for(int64_t M, int K, int N, int pro, int epi);
-/* Rows of the statistics slab the launch for (K, N, pro, epi) will write in the current arithmetic (one per wave for the
+int64_t kd_pwconv_stat_rows_for(int64_t M, int K, int N, int pro, int epi, int with_addend);
+/* Rows of the statistics slab the launch for (K, N, pro, epi, addend given or not) will write in the current arithmetic (one per wave for the
  * weight-resident streaming kernels of kd_gemm_stream.hip, one per 128 matrix rows for the tiled kernels): size the slab and
  * drive kd_bn_finalize_train / kd_bn_bwd_finalize with it.  kd_set_gemm_stream: 0 = tiled kernels only, 1 = streaming
  * kernels only for the shapes that win in isolation, 2 = every covered shape (default; env KD_GEMM_STREAM=0|1|all), 3 = every covered forward shape, tiled data gradients;
@@ -362,6 +362,10 @@ int kd_bf16_bilinear_sum(const void* in0, int H0, int W0, const void* in1, int H
                          void* out, int B, int Ho, int Wo, int C, void* stream);
 int kd_bf16_cls_conv(const void* x, const float* w, const float* b, float* logits_nchw, int64_t M, int HW, int Cin, int NC,
                      void* stream);
+/* weighted-fusion tail (fusion_module.py:115-120): h [M][C] bf16 = relu(attention.0(cat)); out [M][C] bf16 =
+ * w_0 * cat[:, :C] + w_1 * cat[:, C:], (w_0, w_1) = softmax(h . w2^T + b2); w2 [2][C], b2 [2] fp32. */
+int kd_bf16_weighted_tail(const void* h, const void* cat, const float* w2, const float* b2, void* out, int64_t M, int C,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -393,6 +393,42 @@ int cg8_layout(int64_t rows, int C, int& groups, int& slots) {
   return (int)(need < 2048 ? (need < 1 ? 1 : need) : 2048);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// weighted-fusion tail (fusion_module.py:115-120): per pixel the two attention logits a_j = h . w2[j] + b2[j] from the
+// ReLU'd bf16 attention.0 output h [M][C], softmax over the two, out = w_0 * cam_proj + w_1 * lidar_proj with the two
+// projections read from cat [M][2C] (bf16, already normalised + activated).  16-byte lanes: C/8 lanes share a pixel.
+__global__ __launch_bounds__(256) void weighted_tail_bf16_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ cat, const float* __restrict__ w2,
+                                                                 const float* __restrict__ b2, bf16_t* __restrict__ out, int64_t M, int C, int LP) {
+  const int gidx = threadIdx.x % LP, slot = threadIdx.x / LP, slots = 256 / LP;
+  const int c0 = gidx * 8;
+  float w20[8], w21[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { w20[i] = w2[c0 + i]; w21[i] = w2[C + c0 + i]; }
+  const float b20 = b2[0], b21 = b2[1];
+  const int64_t iters = (M + (int64_t)gridDim.x * slots - 1) / ((int64_t)gridDim.x * slots);
+  for (int64_t it = 0; it < iters; ++it) {               // uniform trip count: the shuffles need every lane
+    const int64_t m = (it * gridDim.x + blockIdx.x) * slots + slot;
+    const bool ok = m < M;
+    const int64_t mm = ok ? m : M - 1;
+    float hv[8], cp[8], lp[8];
+    unpack8(ld16(h + mm * C + c0), hv);
+    unpack8(ld16(cat + mm * 2 * C + c0), cp);
+    unpack8(ld16(cat + mm * 2 * C + C + c0), lp);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a0 = fmaf(hv[i], w20[i], a0); a1 = fmaf(hv[i], w21[i], a1); }
+    for (int o = LP >> 1; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
+    a0 += b20; a1 += b21;
+    const float mx = fmaxf(a0, a1);
+    const float e0 = expf(a0 - mx), e1 = expf(a1 - mx);
+    const float w0 = e0 / (e0 + e1), w1 = e1 / (e0 + e1);
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = cp[i] * w0 + lp[i] * w1;
+    if (ok) st16(out + m * C + c0, pack8(r));
+  }
+}
+
 template <int NB>
 int launch_gemm_bf16(GemmBfArgs& g, int ain, int epi, hipStream_t st) {
   const int ntiles = g.N / (32 * NB);
@@ -492,6 +528,20 @@ int kd_bf16_cls_conv(const void* x, const float* w, const float* b, float* logit
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(cls_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, b, logits_nchw, M, HW, Cin, NC);
   return kd_check_launch("kd_bf16_cls_conv");
+}
+
+/* weighted-fusion tail: out [M][C] bf16 = softmax_2(h . w2^T + b2)-weighted sum of the two halves of cat [M][2C] (bf16).
+ * h [M][C] bf16 is the ReLU'd attention.0 output; w2 [2][C], b2 [2] fp32. */
+int kd_bf16_weighted_tail(const void* h, const void* cat, const float* w2, const float* b2, void* out, int64_t M, int C, void* stream) {
+  KD_REQUIRE(h && cat && w2 && b2 && out && M > 0, KD_ERR_ARG, "kd_bf16_weighted_tail: bad args");
+  KD_REQUIRE(C == 64 || C == 128 || C == 256 || C == 512, KD_ERR_SHAPE, "kd_bf16_weighted_tail: C=%d must be 64/128/256/512", C);
+  KD_REQUIRE(kd_aligned16(h) && kd_aligned16(cat) && kd_aligned16(out), KD_ERR_ALIGN, "kd_bf16_weighted_tail: alignment");
+  const int LP = C / 8, slots = 256 / LP;
+  int64_t grid = (M + slots - 1) / slots;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(weighted_tail_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, (const bf16_t*)cat, w2, b2,
+                     (bf16_t*)out, M, C, LP);
+  return kd_check_launch("kd_bf16_weighted_tail");
 }
 
 }  // extern "C"

@@ -63,7 +63,9 @@ template <int PRO, int EPI, int WM, int WN, bool SPLIT>
 // kernel; split: the 128x128 kernels except PRO2, whose two-tensor prologue would spill 46 registers).  The third
 // workgroup is worth 8-12 % on the forward kernels: these loops are latency-bound, not pipe-bound (PMC: matrix pipe
 // busy ~31 %, VALU ~10 %, LDS ~22 % at 2 workgroups / CU).
-__global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 4) ? 3 : 2) : ((PRO == 4 || (PRO == 2 && WM == 4)) ? 2 : 3)) void pw_gemm_kernel(GemmArgs g) {
+// (workgroups per CU by register budget: 3 x 168 registers where the prologue is light; the layer-0-recompute prologue (PRO3) and the
+// two- / three-tensor prologues spill at 168 and run 2 x 256)
+__global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 3 && PRO != 4) ? 3 : 2) : ((PRO == 3 || PRO == 4 || (PRO == 2 && WM == 4)) ? 2 : 3)) void pw_gemm_kernel(GemmArgs g) {
   constexpr int BMt = 64 * WM, BNt = 64 * WN;
   constexpr int AF = BMt / 32, BF = BNt / 32;          // float4 loads per thread per K-tile
   constexpr int SMEM_FLOATS = SPLIT ? (BMt + BNt) * 3 * SPROW / 2 : (BMt + BNt) * LDSLD;
@@ -791,7 +793,8 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs 
     }
     kd_lds_barrier();
     if (wm == 0) {
-      for (int o = 1; o < WM; ++o) {
+#pragma unroll 1
+      for (int o = 1; o < WM; ++o) {         // (one slice at a time: unrolled, hipcc hoists all 3 x 64 LDS reads and spills)
         const float* src = smem + (((o - 1) * WN + wn) * WK + wk) * 4096;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
@@ -849,9 +852,9 @@ int launch_wgrad(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
 }
 
 
-int64_t stat_rows_for(int64_t M, int K, int N, int pro, int epi) {
+int64_t stat_rows_for(int64_t M, int K, int N, int pro, int epi, bool add) {
   if (g_gemm_split.load(std::memory_order_relaxed)) {
-    const int r = kd_gemm_stream_stat_rows(M, K, N, pro, epi);
+    const int r = kd_gemm_stream_stat_rows(M, K, N, pro, epi, add);
     if (r > 0) return r;
   }
   return (M + BM - 1) / BM;
@@ -863,7 +866,7 @@ int64_t stat_rows_for(int64_t M, int K, int N, int pro, int epi) {
 // here, never a silently short or stale reduction downstream (round 2's 3e-4 systematic gradient error).
 int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st, int64_t partial_rows = -1) {
   if (g.partial && (epi == 1 || epi == 2 || epi == 3)) {
-    const int64_t want = stat_rows_for(g.M, g.K, g.N, pro, epi);
+    const int64_t want = stat_rows_for(g.M, g.K, g.N, pro, epi, g.addend != nullptr);
     KD_REQUIRE(partial_rows == want, KD_ERR_ARG,
                "GEMM statistics slab: caller sized %lld rows, this launch (M=%d K=%d N=%d pro=%d epi=%d, %s kernel) writes %lld "
                "-- query kd_pwconv_stat_rows_for() in the same arithmetic / streaming mode as the launch",
@@ -873,7 +876,9 @@ int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st, int64_t partial_r
   const dim3 blk(256);
   g.nt_store = kd_nt_store((size_t)g.M * g.N * sizeof(float));   // (non-temporal LOADS of A measured neutral: not kept)
   // 256x64 tiles when the last column tile would be <= 64 wide (N = 32, 64, 192, ...)
-  const bool tall = ((g.N - 1) % 128) < 64;
+  // (the table-form scatter gradient, PRO4, only ever has N = 128 output columns -- the point MLP's hidden width: square tiles only;
+  // its 256x64 instance needed 124 bytes of scratch and is not built)
+  const bool tall = pro != 4 && ((g.N - 1) % 128) < 64;
   const int64_t M = g.M;
   const int64_t ntile = tall ? ((M + 255) / 256) * ((g.N + 63) / 64) : ((M + 127) / 128) * ((g.N + 127) / 128);
   const bool split = g_gemm_split.load(std::memory_order_relaxed) != 0;
@@ -899,8 +904,11 @@ int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st, int64_t partial_r
   KD_GEMM_CASE(3, 0) KD_GEMM_CASE(3, 1) KD_GEMM_CASE(2, 3)      // LiDAR layer 0 recomputed from the points
   KD_GEMM_CASE(1, 4)                                              // last point-MLP layer + BEV scatter-max (eval)
   KD_GEMM_CASE(0, 5) KD_GEMM_CASE(1, 5)                           // inference: eval BatchNorm + act (+ residual) in the epilogue
-  KD_GEMM_CASE(4, 2)                                              // last point-MLP layer: dgrad with G rebuilt from the tables
 #undef KD_GEMM_CASE
+  if (pro == 4 && epi == 2) {                                     // last point-MLP layer: dgrad with G rebuilt from the tables
+    if (split) hipLaunchKernelGGL((pw_gemm_kernel<4, 2, 2, 2, true>), grid, blk, 0, st, g);
+    else hipLaunchKernelGGL((pw_gemm_kernel<4, 2, 2, 2, false>), grid, blk, 0, st, g);
+  }
   return kd_check_launch("kd_pwconv_gemm");
 }
 
@@ -941,7 +949,7 @@ int64_t kd_pwconv_stat_rows(int64_t M) { return (M + BM - 1) / BM; }
 // ... for the launch the dispatcher will actually make for (K, N, pro, epi) in the current arithmetic: the streaming
 // kernels write one row per wave (<= 1024), the tiled kernels one per 128 matrix rows.  Callers size the slab AND tell
 // kd_bn_finalize_train / kd_bn_bwd_finalize how many rows to sum with this number.
-int64_t kd_pwconv_stat_rows_for(int64_t M, int K, int N, int pro, int epi) { return stat_rows_for(M, K, N, pro, epi); }
+int64_t kd_pwconv_stat_rows_for(int64_t M, int K, int N, int pro, int epi, int with_addend) { return stat_rows_for(M, K, N, pro, epi, with_addend != 0); }
 
 // Forward / dgrad GEMM.  See include/kd_hip.h for the argument contract.
 int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, int pro, int pro_act, const float* p0,
@@ -1022,9 +1030,9 @@ size_t kd_lidar_l1_dgrad_ws_bytes(int64_t M, int K0) {
   return (size_t)(tiled > waves ? tiled : waves) * 4 * K0 * sizeof(float);
 }
 // rows of the BatchNorm-backward slab (`partial`, [rows][2][K0]) kd_lidar_l1_dgrad writes for this shape
-int64_t kd_lidar_l1_dgrad_stat_rows(int64_t M, int N1, int K0) { return kd_pwconv_stat_rows_for(M, N1, K0, 2, 3); }
+int64_t kd_lidar_l1_dgrad_stat_rows(int64_t M, int N1, int K0) { return kd_pwconv_stat_rows_for(M, N1, K0, 2, 3, 0); }
 // ... and kd_lidar_l2_dgrad ([rows][2][K1])
-int64_t kd_lidar_l2_dgrad_stat_rows(int64_t M, int N2, int K1) { return kd_pwconv_stat_rows_for(M, N2, K1, 4, 2); }
+int64_t kd_lidar_l2_dgrad_stat_rows(int64_t M, int N2, int K1) { return kd_pwconv_stat_rows_for(M, N2, K1, 4, 2, 0); }
 
 // m1_out (optional, [4][K0]) = sum_m G0[m][:] * pts[m][j]: with it (and its workspace m1_ws of
 // kd_lidar_l1_dgrad_ws_bytes) the layer-0 weight gradient needs G0 only through these moments, and G0 may be NULL.
@@ -1045,7 +1053,7 @@ int kd_lidar_l1_dgrad(const float* G, int64_t ldg, const float* Y1, int64_t ldy,
   GemmArgs g{G, ldg, Y1, ldy, al, be, ga, msc, msh, 2, mact, Wt, nullptr, G0, ldg0, nullptr, 0,
              pts, 4, sc0, sh0, mean0, invstd0, act0, partial, (int)M, N1, K0, nullptr, w0, b0,
              nullptr, nullptr, nullptr, m1_out ? (float*)m1_ws : nullptr};
-  const int sr = g_gemm_split.load(std::memory_order_relaxed) ? kd_gemm_stream_stat_rows(M, N1, K0, 2, 3) : 0;
+  const int sr = g_gemm_split.load(std::memory_order_relaxed) ? kd_gemm_stream_stat_rows(M, N1, K0, 2, 3, false) : 0;
   const int rc = gemm_launch(g, 2, 3, (hipStream_t)stream, partial_rows);
   if (rc || !m1_out) return rc;
   // one slab row per wave of the streaming kernel, else per output tile: 256 rows when the output is at most 64 wide

@@ -57,4 +57,4 @@ __device__ __forceinline__ void kd_split3(float4 v, uint2& hi, uint2& mid, uint2
 // then uses the tiled kernel), < 0 on error.  kd_stream_stat_rows: rows of the BN-statistics slab that launch writes
 // (0: not covered).
 int kd_gemm_stream_launch(GemmArgs& g, int pro, int epi, hipStream_t st);
-int kd_gemm_stream_stat_rows(int64_t M, int K, int N, int pro, int epi);
+int kd_gemm_stream_stat_rows(int64_t M, int K, int N, int pro, int epi, bool add);

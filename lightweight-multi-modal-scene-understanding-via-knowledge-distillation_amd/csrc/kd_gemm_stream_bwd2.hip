@@ -10,14 +10,13 @@ int kd_stream_bwd2_dispatch(const GemmArgs& g, int kb, int nb, int pro, int epi,
   if (pro == 4 && epi == 2 && kb == 4 && nb == 4) return stream_launch_one<4, 1, 4, 4, 2, false, false>(g, grid, st);
   if (pro != 2 || epi != 2) return 0;
   const bool add = g.addend != nullptr;
-#define KD_B(KB_, KC_, NB_, DB_)                                                           \
-  if (kb == KB_ && nb == NB_) {                                                            \
-    return add ? stream_launch_one<KB_, KC_, NB_, 2, 2, DB_, true>(g, grid, st)            \
-               : stream_launch_one<KB_, KC_, NB_, 2, 2, DB_, false>(g, grid, st);          \
-  }
-  KD_B(1, 1, 1, false) KD_B(1, 1, 2, false) KD_B(1, 1, 4, false)
-  KD_B(2, 1, 1, true) KD_B(2, 1, 2, true) KD_B(2, 1, 4, true)
-  KD_B(4, 1, 1, true) KD_B(4, 1, 2, true) KD_B(4, 1, 4, true)
+  // Only the (K, column tile, residual) combinations that fit 256 registers WITHOUT scratch are built; stream_cfg
+  // (kd_gemm_stream.hip) never promises the others -- the tiled kernel takes those launches.
+#define KD_B(KB_, KC_, NB_, DB_, ADD_)                                                     \
+  if (kb == KB_ && nb == NB_ && add == ADD_) return stream_launch_one<KB_, KC_, NB_, 2, 2, DB_, ADD_>(g, grid, st);
+  KD_B(1, 1, 1, false, false) KD_B(1, 1, 1, false, true) KD_B(1, 1, 2, false, true) KD_B(1, 1, 4, false, false)
+  KD_B(2, 1, 1, true, false) KD_B(2, 1, 2, true, true) KD_B(2, 1, 4, true, false)
+  KD_B(4, 1, 1, true, false) KD_B(4, 1, 2, true, true) KD_B(4, 1, 4, true, false)
 #undef KD_B
   return 0;
 }

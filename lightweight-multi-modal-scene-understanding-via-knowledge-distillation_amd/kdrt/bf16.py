@@ -4,8 +4,8 @@ A second, separately gated mode beside the fp32 contract: eval-mode forward only
 matrices, already normalised and activated (in eval mode every unit is ONE kernel: conv -> BatchNorm -> activation
 [+ residual] -> bf16); accumulation is fp32; parameters and BatchNorm buffers stay the model's fp32 tensors.  The kernels are
 csrc/kd_bf16.hip (C ABI `kd_bf16_*`).  Supported: the multiscale TwinLite encoder + FPN, the spatial LiDAR encoder, concat
-and minimal fusion, the same-resolution head -- what `train_with_fusion_ablation.py` builds (weighted fusion's attention
-tail has no bf16 kernel yet and raises).  Accuracy is that of 8-bit-mantissa activations; tests/test_gpu_bf16.py states the
+minimal and weighted fusion, the same-resolution head -- what `train_with_fusion_ablation.py` builds.  A LiDAR grid
+that differs from the camera map is resized by the fp32 bilinear kernel (the BEV grid stays fp32 in this mode).  Accuracy is that of 8-bit-mantissa activations; tests/test_gpu_bf16.py states the
 measured logit error and argmax agreement against the fp32 path.
 
 The KD step can run its frozen TEACHER through this path (`KDStep(..., teacher_storage="bf16")`): the teacher only supplies
@@ -24,6 +24,17 @@ from .ops import ACT_RELU, ACT_RELU6, P, stream
 def _coef(spec):
     C = spec.bn.running_mean.numel()
     return units._coeffs(spec, None, 0, C, 0, False, None, spec.bn.running_mean.device)
+
+
+_IDENT = {}
+
+
+def _identity(C, dev):
+    """scale = 1, shift = 0: the epilogue coefficients of a convolution that has no BatchNorm (attention.0)."""
+    key = (C, dev)
+    if key not in _IDENT:
+        _IDENT[key] = (torch.ones(C, device=dev), torch.zeros(C, device=dev))
+    return _IDENT[key]
 
 
 def _pw(x, spec, M, res=None, out=None, a_kind=0, m_dev=None):
@@ -67,7 +78,7 @@ def forward_bf16(model, images: torch.Tensor, points: torch.Tensor, return_inter
     """Eval-mode forward of a CompleteSegmentationModel with bf16 activations; returns fp32 logits [B, C, h, w].
     With `return_intermediates` also the two feature maps the KD objective matches (fusion_module.py:260-262's
     `camera_feat` and `lidar_feat`), as fp32 NCHW-shaped views: (logits, {"camera_feat", "lidar_feat", "logits"})."""
-    from src.models.fusion_module import ConcatenationFusion, MinimalFusion, SameResolutionSegmentationHead
+    from src.models.fusion_module import ConcatenationFusion, MinimalFusion, SameResolutionSegmentationHead, WeightedFusion
     ops.require_gpu_tensor(images, "forward_bf16")
     if model.training:
         raise KDError("forward_bf16 is an inference path: call model.eval() first")
@@ -128,8 +139,10 @@ def forward_bf16(model, images: torch.Tensor, points: torch.Tensor, return_inter
     grid = torch.zeros(Bp * Hg * Wg, N2, device=dev, dtype=torch.float32)
     lib.call("kd_bf16_pwconv", P(y1), N1, 0, P(u2.conv.weight), P(u2.conv.bias), P(c2.scale), P(c2.shift), u2.act, None, 0, None, 0, 4,
              Mp, N1, N2, P(counter), None, None, None, None, 0, P(cell), P(grid), N2, stream())
-    if (Hg, Wg) != (cgeom[1], cgeom[2]):
-        raise KDError("bf16 path: the LiDAR grid must match the camera feature map (no resize kernel in this mode)")
+    lidar_map = grid
+    if (Hg, Wg) != (cgeom[1], cgeom[2]):        # fusion_module.py:239-240; the BEV grid is fp32, so the fp32 resize serves
+        lidar_map = torch.empty(Bp * cgeom[1] * cgeom[2], N2, device=dev, dtype=torch.float32)
+        lib.call("kd_bilinear_accum_fwd", P(grid), None, None, ops.ACT_NONE, P(lidar_map), 0, Bp, Hg, Wg, cgeom[1], cgeom[2], N2, stream())
     # ---- fusion (fusion_module.py:242-255) ---------------------------------------------------------------------------------------
     M = cam.shape[0]
     fus = model.fusion
@@ -138,14 +151,32 @@ def forward_bf16(model, images: torch.Tensor, points: torch.Tensor, return_inter
         Cc, Cl = uc.conv.weight.shape[0], ul.conv.weight.shape[0]
         cat = torch.empty(M, Cc + Cl, device=dev, dtype=torch.bfloat16)
         _pw(cam, uc, M, out=cat[:, :Cc])
-        _pw(grid, ul, M, out=cat[:, Cc:], a_kind=1)
+        _pw(lidar_map, ul, M, out=cat[:, Cc:], a_kind=1)
         from src.models.fusion_module import _dw_unit, _pw_unit
         fz, fgeom = _chain(cat, cgeom, [_dw_unit(fus.fuse, 0), _pw_unit(fus.fuse, 3)])
     elif isinstance(fus, MinimalFusion):
         t = _pw(cam, fus.cam_proj.unit(), M)
-        fz, fgeom = _pw(grid, fus.lidar_proj.unit(), M, res=t, a_kind=1), cgeom
+        fz, fgeom = _pw(lidar_map, fus.lidar_proj.unit(), M, res=t, a_kind=1), cgeom
+    elif isinstance(fus, WeightedFusion):
+        # fusion_module.py:115-120: both projections into one [M, 2C] buffer, attention.0 + ReLU as a plain bf16 GEMM
+        # (identity "BatchNorm" coefficients), then conv 2C->2 + softmax + the weighted sum in one streaming pass
+        uc, ul = fus.cam_proj.unit(), fus.lidar_proj.unit()
+        C = uc.conv.weight.shape[0]
+        if ul.conv.weight.shape[0] != C:
+            raise KDError("bf16 path: weighted fusion needs equal projection widths")
+        cat = torch.empty(M, 2 * C, device=dev, dtype=torch.bfloat16)
+        _pw(cam, uc, M, out=cat[:, :C])
+        _pw(lidar_map, ul, M, out=cat[:, C:], a_kind=1)
+        a0, a2 = fus.attention[0], fus.attention[2]
+        one, zero = _identity(C, dev)
+        h = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        lib.call("kd_bf16_pwconv", P(cat), 2 * C, 0, P(a0.weight), P(a0.bias), P(one), P(zero), ACT_RELU, P(h), C, None, 0, 0, M, 2 * C, C,
+                 None, None, None, None, None, 0, None, None, 0, stream())
+        fz = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        lib.call("kd_bf16_weighted_tail", P(h), P(cat), P(a2.weight), P(a2.bias), P(fz), M, C, stream())
+        fgeom = cgeom
     else:
-        raise KDError("bf16 path: weighted fusion is not supported (its attention tail has no bf16 kernel)")
+        raise KDError(f"bf16 path: fusion block {type(fus).__name__} is not supported")
     # ---- head (fusion_module.py:162-173) -------------------------------------------------------------------------------------------
     hz, hgeom = _chain(fz, fgeom, model.head.block[0].units() + model.head.block[1].units())
     cls = model.head.cls
@@ -153,6 +184,6 @@ def forward_bf16(model, images: torch.Tensor, points: torch.Tensor, return_inter
     logits = torch.empty(B, NC, hgeom[1], hgeom[2], device=dev, dtype=torch.float32)
     lib.call("kd_bf16_cls_conv", P(hz), P(cls.weight), P(cls.bias), P(logits), hz.shape[0], hgeom[1] * hgeom[2], Cin_c, NC, stream())
     if return_intermediates:       # the camera map is widened once (layout plumbing); the BEV grid is fp32 already
-        return logits, {"camera_feat": ops.nchw_from_matrix(cam.float(), cgeom), "lidar_feat": ops.nchw_from_matrix(grid, (Bp, Hg, Wg)),
+        return logits, {"camera_feat": ops.nchw_from_matrix(cam.float(), cgeom), "lidar_feat": ops.nchw_from_matrix(lidar_map, (Bp, cgeom[1], cgeom[2])),
                         "logits": logits}
     return logits

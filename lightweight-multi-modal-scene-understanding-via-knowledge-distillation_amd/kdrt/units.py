@@ -86,7 +86,7 @@ def unit_forward(spec: UnitSpec, inp, training: bool, y: Optional[torch.Tensor] 
         partial, rows = None, 0
         if training:
             pro = 3 if inp.virt is not None else (1 if inp.bnc is not None else 0)
-            rows = lib.kd_pwconv_stat_rows_for(M, K, N, pro, 1)         # streaming kernels: one row per wave; tiled: per 128 rows
+            rows = lib.kd_pwconv_stat_rows_for(M, K, N, pro, 1, 0)         # streaming kernels: one row per wave; tiled: per 128 rows
             partial = torch.empty(rows * 2 * N, device=dev, dtype=torch.float32)
         if inp.virt is not None:
             ops.l1_fwd(inp, w, y, bias=b, epi=1 if training else 0, partial=partial, partial_rows=rows, m_dev=m_dev)
@@ -349,7 +349,7 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
                 g_in = ("G", gin, part_in, rows_in)
             elif inp.bnc is not None:
                 gin = torch.empty(M, K, device=dev, dtype=torch.float32)
-                rows_in = lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2)     # (reduction width N, output width K: the data gradient)
+                rows_in = lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2, int(addend is not None))     # (reduction width N, output width K: the data gradient)
                 part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
                 ops.pw_gemm(t, Wt, gin, M=M, K=N, N=K, A2=y, pro=2, pro_act=mact, p=(al, be, ga, msc, msh),
                             addend=addend, epi=2, X=inp.raw, esc=inp.sc, esh=inp.sh, emean=inp.bnc.mean,
@@ -429,7 +429,7 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
             Wd = rec.w.view(Cin, N16)                                     # dgrad operand [N = Cin, K = Cout*16] as stored
             if inp.bnc is not None:
                 gin = torch.empty(inp.M, Cin, device=dev, dtype=torch.float32)
-                rows_in = lib.kd_pwconv_stat_rows_for(inp.M, N16, Cin, 0, 2)
+                rows_in = lib.kd_pwconv_stat_rows_for(inp.M, N16, Cin, 0, 2, int(addend is not None))
                 part_in = torch.empty(rows_in * 2 * Cin, device=dev, dtype=torch.float32)
                 ops.pw_gemm(dcol, Wd, gin, M=inp.M, K=N16, N=Cin, addend=addend, epi=2, X=inp.raw, esc=inp.sc, esh=inp.sh,
                             emean=inp.bnc.mean, einv=inp.bnc.invstd, epi_act=inp.act, partial=part_in, partial_rows=rows_in)
@@ -715,7 +715,7 @@ class WeightedFuseFn(torch.autograd.Function):
         dw1, w1_dir = gradsink.out_for(ctx.w1)
         ops.pw_wgrad(gh, cat, dw1, M=M, N=C, K=2 * C, d_mode=0, a_mode=1, a_act=ACT_RELU, asc=comb.scale, ash=comb.shift)
         w1t = ops.transpose(ctx.w1.view(C, 2 * C))
-        rows = lib.kd_pwconv_stat_rows_for(M, C, 2 * C, 0, 2)           # (reduction width C, output width 2C)
+        rows = lib.kd_pwconv_stat_rows_for(M, C, 2 * C, 0, 2, 1)           # (reduction width C, output width 2C)
         partial = torch.empty(rows * 2 * 2 * C, device=dev, dtype=torch.float32)
         gcat = torch.empty(M, 2 * C, device=dev, dtype=torch.float32)
         ops.pw_gemm(gh, w1t, gcat, M=M, K=C, N=2 * C, pro=0, addend=dcat, epi=2, X=cat, esc=comb.scale, esh=comb.shift,

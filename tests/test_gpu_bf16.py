@@ -15,8 +15,9 @@ LOGIT_TOL_REL = 1.5e-2
 ARGMAX_MIN = 0.99
 
 
-@pytest.mark.parametrize("fusion", ("concat", "minimal"))
-@pytest.mark.parametrize("shape", ((2, 64, 700, 16), (2, 256, 5000, 64)))
+# the third shape has an 8 x 8 BEV grid under a 16 x 16 camera map: the bilinear LiDAR resize of fusion_module.py:239-240
+@pytest.mark.parametrize("fusion", ("concat", "minimal", "weighted"))
+@pytest.mark.parametrize("shape", ((2, 64, 700, 16), (2, 256, 5000, 64), (2, 64, 700, 8)))
 def test_bf16_forward_against_fp32_and_oracle(fusion, shape):
     from kdrt.bf16 import forward_bf16
     B, HW, N, G = shape
@@ -46,9 +47,9 @@ def test_bf16_mode_is_gated():
     from kdrt import KDError
     from kdrt.bf16 import forward_bf16
     images, pts, _ = O.make_inputs(2, 64, 256, 16, 3)
-    m = build_product("weighted", 16)
+    m = build_product("concat", 16, output_mode="x4")
     m.eval()
-    with pytest.raises(KDError):                     # no bf16 kernel for the attention tail: fails loudly, no fallback
+    with pytest.raises(KDError):                     # no bf16 kernels for the transposed-convolution head: loud, no fallback
         forward_bf16(m, images.cuda(), pts.cuda())
     m2 = build_product("concat", 16)
     m2.train()
@@ -65,7 +66,8 @@ KD_LOSS_TOL_REL = 5e-2
 KD_GRAD_COS_MIN = 0.995
 
 
-def test_kd_step_with_bf16_teacher():
+@pytest.mark.parametrize("teacher_fusion", ("concat", "weighted"))
+def test_kd_step_with_bf16_teacher(teacher_fusion):
     from kdrt.kd import KDStep
     from kdrt.optim import FusedAdamW
     B, HW, N, G = 2, 256, 5000, 64
@@ -74,8 +76,8 @@ def test_kd_step_with_bf16_teacher():
     cw = torch.tensor([0.4, 3.5]).cuda()
     res = {}
     for storage in ("fp32", "bf16"):
-        teacher = build_product("concat", G)
-        load_random_state(teacher, "concat", 11)
+        teacher = build_product(teacher_fusion, G)
+        load_random_state(teacher, teacher_fusion, 11)
         student = build_product("weighted", G)
         load_random_state(student, "weighted", 12)
         student.train()

@@ -41,7 +41,7 @@ def test_forward_prologues_and_stats(M, K, N):
         ref_in = A.double() if pro == 0 else _act(A.double() * sc.double() + sh.double(), act)
         want = ref_in @ W.double().t() + (bias.double() if use_bias else 0)
         C = torch.full((M, N + 4), 7.0, device="cuda")[:, :N]         # strided output; the pad must stay untouched
-        rows = ops.lib.kd_pwconv_stat_rows_for(M, K, N, pro, epi)        # rows the launch for this shape writes
+        rows = ops.lib.kd_pwconv_stat_rows_for(M, K, N, pro, epi, 0)     # rows the launch for this shape writes
         partial = torch.zeros(rows * 2 * N, device="cuda") if epi else None
         ops.pw_gemm(Ad, W.cuda(), C, M=M, K=K, N=N, pro=pro, pro_act=act, p=(sc.cuda(), sh.cuda(), None, None, None),
                     bias=bias.cuda() if use_bias else None, epi=epi, partial=partial, partial_rows=rows)
@@ -72,7 +72,7 @@ def test_dgrad_and_wgrad(M, K, N):
     dx = (dy @ d(W)) * (zx > 0).double()
     c = lambda t: t.cuda()
     gin = torch.empty(M, K, device="cuda")
-    rows = ops.lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2)              # (reduction width N, output width K)
+    rows = ops.lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2, 0)           # (reduction width N, output width K)
     part = torch.zeros(rows * 2 * K, device="cuda")
     Wt = ops.transpose(c(W))                                           # [K][N]
     ops.pw_gemm(c(G), Wt, gin, M=M, K=N, N=K, A2=c(Y), pro=2, pro_act=1, p=(c(al), c(be), c(ga), c(msc), c(msh)), epi=2,
@@ -120,7 +120,7 @@ def test_streaming_dgrad_same_bits_as_tiled(M, K, N, epi, with_addend):
     esc, esh, mean, inv = (c(torch.rand(K, generator=g) + 0.5) for _ in range(4))
 
     def run():
-        rows = ops.lib.kd_pwconv_stat_rows_for(M, N, K, 2, epi)
+        rows = ops.lib.kd_pwconv_stat_rows_for(M, N, K, 2, epi, int(with_addend))
         gin = torch.full((M, K), float("nan"), device="cuda")
         part = torch.zeros(rows * 2 * K, device="cuda") if epi == 2 else None
         ops.pw_gemm(G, Wt, gin, M=M, K=N, N=K, A2=Y, pro=2, pro_act=2, p=(al, be, ga, msc, msh), addend=add if with_addend else None,
@@ -190,9 +190,9 @@ def test_statistics_slab_sized_for_the_other_kernel_form_is_refused():
     Cout = torch.empty(M, N, device="cuda")
     prev = lib.kd_set_gemm_stream(2)
     try:
-        r_stream = lib.kd_pwconv_stat_rows_for(M, K, N, 0, 1)
+        r_stream = lib.kd_pwconv_stat_rows_for(M, K, N, 0, 1, 0)
         lib.kd_set_gemm_stream(0)
-        r_tiled = lib.kd_pwconv_stat_rows_for(M, K, N, 0, 1)
+        r_tiled = lib.kd_pwconv_stat_rows_for(M, K, N, 0, 1, 0)
         assert r_tiled == (M + 127) // 128 and r_stream != r_tiled
         part = torch.zeros(max(r_stream, r_tiled) * 2 * N, device="cuda")
         for mode, good, bad in ((0, r_tiled, r_stream), (2, r_stream, r_tiled)):
@@ -201,16 +201,18 @@ def test_statistics_slab_sized_for_the_other_kernel_form_is_refused():
             for wrong in (bad, good - 1, 0):
                 with pytest.raises(KDError, match="statistics slab"):
                     ops.pw_gemm(A, W, Cout, M=M, K=K, N=N, epi=1, partial=part, partial_rows=wrong)
-        # data gradient through an activation (epi 2)
+        # data gradient through an activation (epi 2): reduction width 128, output width 128 (an instance the dispatcher selects)
+        K = 128
+        W = torch.randn(N, K, generator=g).cuda()
         G, Y, X = (torch.randn(M, n, generator=g).cuda() for n in (N, N, K))
         v = lambda n: torch.rand(n, generator=g).cuda() + 0.5
         al, be, ga, msc, msh, esc, esh, mean, inv = v(N), v(N), v(N), v(N), v(N), v(K), v(K), v(K), v(K)
         Wt = ops.transpose(W)
         gin = torch.empty(M, K, device="cuda")
         lib.kd_set_gemm_stream(2)
-        rs = lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2)
+        rs = lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2, 0)
         lib.kd_set_gemm_stream(0)
-        rt = lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2)
+        rt = lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2, 0)
         assert rs != rt
         part2 = torch.zeros(max(rs, rt) * 2 * K, device="cuda")
         kw = dict(M=M, K=N, N=K, A2=Y, pro=2, pro_act=1, p=(al, be, ga, msc, msh), epi=2, X=X, esc=esc, esh=esh, emean=mean,
@@ -222,6 +224,9 @@ def test_statistics_slab_sized_for_the_other_kernel_form_is_refused():
         with pytest.raises(KDError, match="statistics slab"):
             ops.pw_gemm(G, Wt, gin, partial_rows=rt, **kw)            # and the other way round
         ops.pw_gemm(G, Wt, gin, partial_rows=rs, **kw)
+        # instances that hipcc can only build with scratch are never selected: the same launch WITH a residual gradient takes
+        # the tiled kernel in both modes (csrc/kd_gemm_stream.hip: stream_cfg)
+        assert lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2, 1) == rt
         torch.cuda.synchronize()
     finally:
         lib.kd_set_gemm_stream(prev)

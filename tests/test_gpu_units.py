@@ -148,9 +148,10 @@ def test_lidar_encoder(n, grid, pad):
         assert max_err(p.grad, want)[1] < 5 * TOL, name
 
 
-def test_lidar_encoder_eval_mode_backward():
+def test_lidar_encoder_eval_mode_backward(monkeypatch):
     """eval() with autograd on (frozen-BatchNorm fine-tuning): running statistics in the forward, real gradients back."""
     from src.models.lidar_encoder import LiDAREncoder
+    from kdrt import units
     enc = LiDAREncoder(encoder_type="spatial", grid_size=(16, 16))
     st = _rand_state(enc, 33)
     enc = enc.cuda().eval()
@@ -160,7 +161,10 @@ def test_lidar_encoder_eval_mode_backward():
     yo = O.spatial_lidar_encoder(pts, so, "encoder.", (16, 16), False)
     assert max_err(y, yo)[1] < TOL
     with torch.no_grad():
-        assert torch.equal(enc(pts.cuda()).view(torch.int32), y.detach().view(torch.int32))    # inference path: same bits
+        # the one-kernel inference encoder sums each dot product in its own order: oracle tolerance, not bits
+        assert max_err(enc(pts.cuda()), yo)[1] < TOL
+        monkeypatch.setattr(units, "_LIDAR_FUSED_INFER", False)
+        assert torch.equal(enc(pts.cuda()).view(torch.int32), y.detach().view(torch.int32))    # layer-by-layer: same bits
     up = torch.randn(yo.shape, generator=torch.Generator().manual_seed(8))
     (y * up.cuda()).sum().backward()
     (yo * up).sum().backward()

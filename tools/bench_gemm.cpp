@@ -60,10 +60,10 @@ int main(int argc, char** argv) {
       for (int i = 0; i < reps; ++i) fn();
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / reps; };
-    float t1 = timeit([&] { RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, nullptr, C, s.N, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, partial, kd_pwconv_stat_rows_for(s.M, s.K, s.N, 1, 1), s.M, s.K, s.N, nullptr, nullptr)); });
+    float t1 = timeit([&] { RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, nullptr, C, s.N, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, partial, kd_pwconv_stat_rows_for(s.M, s.K, s.N, 1, 1, 0), s.M, s.K, s.N, nullptr, nullptr)); });
     float t0 = timeit([&] { RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, nullptr, C, s.N, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, s.M, s.K, s.N, nullptr, nullptr)); });
     // dgrad: A = G [M,N], A2 = Y [M,N], W^T stored [K][N], out [M,K], X(epi) [M,K]
-    float t2 = timeit([&] { RC(kd_pwconv_gemm(A, s.N, A2, s.N, 2, 0, al, be, ga, nullptr, nullptr, W, nullptr, C, s.K, nullptr, 0, 2, X, s.K, sc, sh, mean, inv, 2, partial, kd_pwconv_stat_rows_for(s.M, s.N, s.K, 2, 2), s.M, s.N, s.K, nullptr, nullptr)); });
+    float t2 = timeit([&] { RC(kd_pwconv_gemm(A, s.N, A2, s.N, 2, 0, al, be, ga, nullptr, nullptr, W, nullptr, C, s.K, nullptr, 0, 2, X, s.K, sc, sh, mean, inv, 2, partial, kd_pwconv_stat_rows_for(s.M, s.N, s.K, 2, 2, 0), s.M, s.N, s.K, nullptr, nullptr)); });
     float t3 = timeit([&] { RC(kd_pwconv_wgrad(A, s.N, A2, s.N, 2, 0, al, be, ga, nullptr, nullptr, X, s.K, 1, 2, sc, sh, C, s.M, s.N, s.K, ws, wsb, nullptr)); });
     if (split) {   // same forward with both arithmetics: max |diff| relative to max |value|
       const size_t n = std::min((size_t)s.M, (size_t)65536) * s.N;
@@ -80,7 +80,7 @@ int main(int argc, char** argv) {
     if (auto rd = (int (*)(unsigned long long*, int))dlsym(RTLD_DEFAULT, "kd_dbg_read")) {   // dev build with phase counters
       unsigned long long c[8];
       rd(c, 1);
-      RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, nullptr, C, s.N, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, partial, kd_pwconv_stat_rows_for(s.M, s.K, s.N, 1, 1), s.M, s.K, s.N, nullptr, nullptr));
+      RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, nullptr, C, s.N, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, partial, kd_pwconv_stat_rows_for(s.M, s.K, s.N, 1, 1, 0), s.M, s.K, s.N, nullptr, nullptr));
       rd(c, 1);
       const double t = (double)c[6];
       printf("    phases (cycles/tile, wave 0): load-wait+transform %.0f | barrier %.0f | split+LDS %.0f | barrier %.0f | MFMA %.0f | epilogue %.0f | tiles %.0f\n",

@@ -58,17 +58,17 @@ int main(int argc, char** argv) {
       const int epi = variant == 0 ? 1 : (variant == 1 ? 0 : 5);
       auto run = [&](float* out, float* part) {
         if (s.kind == 1)
-          RC(kd_lidar_l1_fwd(pts, w0, b0, sc, sh, 1, W, bias, out, s.N, epi, part, kd_pwconv_stat_rows_for(s.M, s.K, s.N, 3, epi), s.M, s.K, s.N, nullptr, nullptr));
+          RC(kd_lidar_l1_fwd(pts, w0, b0, sc, sh, 1, W, bias, out, s.N, epi, part, kd_pwconv_stat_rows_for(s.M, s.K, s.N, 3, epi, 0), s.M, s.K, s.N, nullptr, nullptr));
         else
           RC(kd_pwconv_gemm(A, s.K, nullptr, 0, 1, 2, sc, sh, nullptr, nullptr, nullptr, W, bias, out, s.N, epi == 5 ? add : nullptr, s.N, epi,
-                            nullptr, 0, esc, esh, nullptr, nullptr, 1, part, kd_pwconv_stat_rows_for(s.M, s.K, s.N, 1, epi), s.M, s.K, s.N, nullptr, nullptr));
+                            nullptr, 0, esc, esh, nullptr, nullptr, 1, part, kd_pwconv_stat_rows_for(s.M, s.K, s.N, 1, epi, 0), s.M, s.K, s.N, nullptr, nullptr));
       };
       kd_set_gemm_stream(0);
-      const long rows0 = kd_pwconv_stat_rows_for(s.M, s.K, s.N, s.kind ? 3 : 1, epi);
+      const long rows0 = kd_pwconv_stat_rows_for(s.M, s.K, s.N, s.kind ? 3 : 1, epi, 0);
       CK(hipMemset(C2, 0xff, (size_t)s.M * s.N * 4));
       float t_old = timeit([&] { run(C2, partial2); });
       kd_set_gemm_stream(2);
-      const long rows1 = kd_pwconv_stat_rows_for(s.M, s.K, s.N, s.kind ? 3 : 1, epi);
+      const long rows1 = kd_pwconv_stat_rows_for(s.M, s.K, s.N, s.kind ? 3 : 1, epi, 0);
       CK(hipMemset(C, 0xee, (size_t)s.M * s.N * 4));
       float t_new = timeit([&] { run(C, partial); });
       if (auto rd = (int (*)(unsigned long long*, int))dlsym(RTLD_DEFAULT, "kd_stream_dbg_read")) {   // dev build with phase stamps
@@ -116,14 +116,14 @@ int main(int argc, char** argv) {
       const double by = 4.0 * ((double)s.M * s.K * 2 + (double)s.M * s.N * (epi == 2 ? 2 : 1));
       auto run = [&](float* out, float* part) {
         RC(kd_pwconv_gemm(A, s.K, add, s.K, 2, 2, al, be, ga, sc, sh, W, nullptr, out, s.N, nullptr, 0, epi, epi == 2 ? add : nullptr, s.N, esc, esh,
-                          mean, inv, 2, part, kd_pwconv_stat_rows_for(s.M, s.K, s.N, 2, epi), s.M, s.K, s.N, nullptr, nullptr));
+                          mean, inv, 2, part, kd_pwconv_stat_rows_for(s.M, s.K, s.N, 2, epi, 0), s.M, s.K, s.N, nullptr, nullptr));
       };
       kd_set_gemm_stream(0);
-      const long rows0 = kd_pwconv_stat_rows_for(s.M, s.K, s.N, 2, epi);
+      const long rows0 = kd_pwconv_stat_rows_for(s.M, s.K, s.N, 2, epi, 0);
       CK(hipMemset(C2, 0xff, (size_t)s.M * s.N * 4));
       float t_old = timeit([&] { run(C2, partial2); });
       kd_set_gemm_stream(2);
-      const long rows1 = kd_pwconv_stat_rows_for(s.M, s.K, s.N, 2, epi);
+      const long rows1 = kd_pwconv_stat_rows_for(s.M, s.K, s.N, 2, epi, 0);
       CK(hipMemset(C, 0xee, (size_t)s.M * s.N * 4));
       float t_new = timeit([&] { run(C, partial); });
       const size_t n = (size_t)s.M * s.N;

@@ -20,7 +20,7 @@ for M in (8192, 16384, 16384 + 77):
     xhat = (d(X) - d(mean)) * d(inv)
     c = lambda t: t.cuda()
     gin = torch.empty(M, K, device="cuda")
-    rows = ops.lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2)
+    rows = ops.lib.kd_pwconv_stat_rows_for(M, N, K, 2, 2, 0)
     part = torch.zeros(rows * 2 * K, device="cuda")
     Wt = ops.transpose(c(W))
     ops.pw_gemm(c(G), Wt, gin, M=M, K=N, N=K, A2=c(Y), pro=2, pro_act=0, p=(c(al), c(be), c(ga), None, None), epi=2,
