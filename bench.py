@@ -139,7 +139,30 @@ def bf16_forward_bench(args, dev, images, pts, steps):
         r32, z32 = rate(lambda: model(images, pts))
     r16, z16 = rate(lambda: forward_bf16(model, images, pts))
     rng = float(z32.max() - z32.min())
-    return {"metric": "concat-fusion forward frames/sec, bf16 activations in HBM (fp32 accumulate)", "dtype": "bf16",
+    # per-kernel-family HIP-event timing of one more forward (events on the launch stream): the bf16 mode's own roofline
+    from kdrt import ops
+    ops.PROFILE = []
+    forward_bf16(model, images, pts)
+    torch.cuda.synchronize()
+    recs, ops.PROFILE = ops.PROFILE, None
+    fam = {}
+    for rec in recs:
+        kind, flops, nbytes, secs, _ = ops.prof_scaled(rec)
+        f = fam.setdefault(kind, [0.0, 0.0, 0.0, 0])
+        f[0] += flops; f[1] += nbytes; f[2] += secs; f[3] += 1
+    top = max(fam, key=lambda k: fam[k][2])
+    tot_b, tot_s = sum(f[1] for f in fam.values()), sum(f[2] for f in fam.values())
+    roof = {"bound": "hbm", "kernel": {"bf16_pw": "pw_gemm_bf16_kernel (1x1 conv / point MLP, one bf16 MFMA product per element)",
+                                       "bf16_dw": "dw_bf16_kernel (depthwise 3x3)"}.get(top, top),
+            "achieved": round(fam[top][1] / fam[top][2] / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(fam[top][1] / fam[top][2] / 1e9 / HBM_PEAK_GBPS, 4), "launches": fam[top][3],
+            "traffic": None, "algorithmic_bytes_per_forward": int(fam[top][1]),
+            "executed_bf16_tflops": round(fam[top][0] / fam[top][2] / 1e12, 1),
+            "all_bf16_kernels": {"achieved": round(tot_b / tot_s / 1e9, 1), "frac": round(tot_b / tot_s / 1e9 / HBM_PEAK_GBPS, 4),
+                                 "ms": round(tot_s * 1e3, 3), "launches": sum(f[3] for f in fam.values())},
+            "by_family": {k: {"ms": round(f[2] * 1e3, 3), "GB/s": round(f[1] / f[2] / 1e9, 1), "launches": f[3]} for k, f in sorted(fam.items())},
+            "note": "algorithmic bytes = every bf16/fp32 operand and result of a launch counted once; the fp32 point sort is outside these families"}
+    return {"metric": "concat-fusion forward frames/sec, bf16 activations in HBM (fp32 accumulate)", "dtype": "bf16", "roofline": roof,
             "value": round(r16, 1), "unit": "frames/s", "fp32_forward_frames_per_s": round(r32, 1), "speedup_vs_fp32_forward": round(r16 / r32, 2),
             "steps": steps, "per_gpu_batch": args.batch, "points_per_frame": args.points,
             "max_abs_logit_error_vs_fp32": float(f"{float((z16 - z32).abs().max()):.3e}"), "logit_range": float(f"{rng:.4g}"),
@@ -247,6 +270,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-selfcheck", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write the profiled GEMM launches one per line to this file")
     ap.add_argument("--no-bf16-forward", action="store_true", help="skip the bf16-storage forward line (configs[1])")
     ap.add_argument("--force-reducer", action="store_true",
                     help="--gpus 1 only: bring up RCCL with a world of one rank and run the timed steps WITH the bucketed "
@@ -424,13 +448,21 @@ def main():
         # (split: 6 bf16 MFMA products per fp32 product -> 2500 / 6 TFLOP/s fp32-equivalent) and the 8 TB/s HBM peak
         pipe_peak = (MFMA_BF16_PEAK_TFLOPS / 6.0 if arith == "split" else MFMA_F32_PEAK_TFLOPS) * 1e12
         groups = {}
+        per_launch = []
         for rec in recs:
             kind, flops, nbytes, secs, M = ops.prof_scaled(rec)      # compacted-point launches: actual row count
+            per_launch.append((kind, M, flops, nbytes, secs))
             a = agg.setdefault(kind, [0.0, 0.0, 0.0, 0])
             a[0] += flops; a[1] += nbytes; a[2] += secs; a[3] += 1
             grp = "lidar_point_mlp" if M == args.batch * args.points else "camera_fpn_fusion_head"
             q = groups.setdefault(grp, [0.0, 0.0, 0.0, 0.0, 0])
             q[0] += flops; q[1] += nbytes; q[2] += secs; q[3] += max(flops / pipe_peak, nbytes / (HBM_PEAK_GBPS * 1e9)); q[4] += 1
+        if args.dump_launches:           # dev aid: the two profiled steps launch by launch (nominal rows, N*K, time, rates)
+            with open(args.dump_launches, "w") as f:
+                f.write("kind        rows        N*K   us      GB/s   fp32-equiv TFLOP/s   floor us (max of pipe, HBM)\n")
+                for kind, M, flops, nbytes, secs in per_launch:
+                    floor = max(flops / pipe_peak, nbytes / (HBM_PEAK_GBPS * 1e9))
+                    f.write(f"{kind:10s} {M:9d} {int(flops / (2.0 * max(M, 1))):9d} {secs*1e6:8.1f} {nbytes/secs/1e9:8.1f} {flops/secs/1e12:8.1f} {floor*1e6:10.1f}\n")
         g = agg.get("pw_gemm", [0, 0, 1e-9, 0])
         w = agg.get("pw_wgrad", [0, 0, 1e-9, 0])
         lb = agg.get("lidar_bwd", None)

@@ -79,6 +79,9 @@ int kd_pwconv_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, in
                     const float* A, int64_t lda, int a_mode, int a_act, const float* asc, const float* ash,
                     float* dW, int64_t M, int N, int K, void* ws, size_t ws_bytes, void* stream);
 int kd_transpose(const float* in, float* out, int R, int C, void* stream);
+/* the same for n weights in one launch: table = device int64 [n][5] {in pointer, out pointer, R, C, first 256-element block of
+ * this matrix}, first blocks ascending from 0, nblocks = sum of ceil(R*C/256) */
+int kd_transpose_batch(const int64_t* table, int n, int nblocks, void* stream);
 
 /* ---- stem 3x3/s2 conv (camera_encoder.py:63-67), NCHW image in, NHWC raw out, Cout == 32 ---- */
 int64_t kd_stem_stat_rows(int64_t npix_out);
@@ -162,6 +165,13 @@ int kd_lidar_l2_fwd_scatter(const float* A, int64_t lda, const float* sc1, const
  * that its accumulators are layer 2's operand fragments).  Split arithmetic; zeroes `grid`; sc / sh = kd_bn_eval_coeffs. */
 int kd_lidar_mlp_scatter_infer_supported(int C0, int C1, int C2);
 int kd_lidar_mlp_scatter_infer(const float* pts, const int* cell, const int* p_dev, const float* w0, const float* b0,
+                               const float* sc0, const float* sh0, const float* W1, const float* bias1, const float* sc1,
+                               const float* sh1, const float* W2, const float* bias2, const float* sc2, const float* sh2,
+                               float* grid, int64_t ncells, int64_t P, int C0, int C1, int C2, void* stream);
+/* the same encoder in the bf16-storage inference mode (operands rounded to bf16 once, one MFMA product, fp32 accumulate, fp32
+ * grid): replaces kd_bf16_pwconv(a_kind 3) + kd_bf16_pwconv(epi 4) and the bf16 [P, 128] tensor between them */
+int kd_bf16_lidar_mlp_scatter_supported(int C0, int C1, int C2);
+int kd_bf16_lidar_mlp_scatter(const float* pts, const int* cell, const int* p_dev, const float* w0, const float* b0,
                                const float* sc0, const float* sh0, const float* W1, const float* bias1, const float* sc1,
                                const float* sh1, const float* W2, const float* bias2, const float* sc2, const float* sh2,
                                float* grid, int64_t ncells, int64_t P, int C0, int C1, int C2, void* stream);
@@ -319,6 +329,9 @@ int kd_seg_loss_fwd_bwd(const float* zs, const float* zt, const int64_t* target,
 size_t kd_mse_ws_bytes(int64_t n);
 int kd_mse_fwd_bwd(const float* a, const float* b, int64_t n, float gcoef, const float* gscale_dev, float* loss,
                    float* da, void* ws, size_t ws_bytes, void* stream);
+/* value of the KD objective from its parts: total = ce_kl[0] + ckl * ce_kl[1] + beta * (mse_c[0] + mse_l[0]) (either MSE may be
+ * NULL = 0), every operation rounded to fp32 in that order */
+int kd_kd_total(const float* ce_kl, const float* mse_c, const float* mse_l, float ckl, float beta, float* total, void* stream);
 int kd_argmax_confusion(const float* logits, const int64_t* target, int ignore_index, uint64_t* conf,
                         int64_t* pred, int B, int NC, int HW, void* stream);
 int kd_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

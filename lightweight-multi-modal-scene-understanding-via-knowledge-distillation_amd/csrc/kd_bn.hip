@@ -35,9 +35,17 @@ __global__ void slab_prereduce_kernel(float* partial, int rows, int C, int pstri
   }
 }
 
-// returns the row step the finalize kernel must use (1 = slab untouched)
+// returns the row step the finalize kernel must use (1 = slab untouched).  The finalize kernels walk the slab with FRL = 64 row
+// lanes per channel and FCW = 16 channels per workgroup (a 2048-row slab -- what the streaming GEMMs and the depthwise kernels
+// leave -- is 32 rows per lane, 16 in flight), so only slabs above 8192 rows need the first stage: one launch per BatchNorm
+// instead of two, 58 launches fewer per KD step.  Measured per BatchNorm (round 3, rocprofv3 averages over the step's 58
+// finalizes): the two launches of rounds 1-2: 6.4 + 6.5 us; one launch, 64 channels x 16 row lanes: 16.4 us; 16 x 64 (this):
+// 14.7 us; 8 x 128 with all 16 rows of a lane in flight: 17.6-21.2 us; a single launch whose last workgroup (ticket counter)
+// finalizes: 20 us (its device-scope release / acquire fences write back and invalidate L2).  I.e. the single launch costs
+// ~0.1 ms per step more GPU time than the pair and saves 58 launches of host work; nothing here is bandwidth.
+constexpr int FCW = 16, FRL = 64, FUN = 8;
 static int slab_prereduce(float* partial, int& rows, int C, int pstride, hipStream_t st) {
-  if (rows <= 64) return 1;
+  if (rows <= 8192) return 1;
   int group = 1;
   while (group * group < rows) ++group;                      // ~sqrt(rows)
   const int ngroups = (rows + group - 1) / group;
@@ -46,27 +54,49 @@ static int slab_prereduce(float* partial, int& rows, int C, int pstride, hipStre
   return group;
 }
 
+// block (FCW, FRL): lane y of channel c sums rows y, y+FRL, ... (FUN rows in flight); lane 0 then adds the FRL partial sums in order
 __device__ __forceinline__ void reduce_slab2(const float* partial, int rows, int rstep, int C, int pstride, int c,
-                                             double& s1, double& s2, double (*sm)[2][64]) {
+                                             double& s1, double& s2, double (*sm)[2][FCW]) {
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int r = threadIdx.y; r < rows; r += 4) {
-      a += (double)partial[((int64_t)r * rstep * 2 + 0) * pstride + c];
-      b += (double)partial[((int64_t)r * rstep * 2 + 1) * pstride + c];
+  if (c < C) {
+    int r = threadIdx.y;
+    for (; r + (FUN - 1) * FRL < rows; r += FUN * FRL) {
+      float v[FUN][2];
+#pragma unroll
+      for (int u = 0; u < FUN; ++u) {
+        v[u][0] = partial[((int64_t)(r + u * FRL) * rstep * 2 + 0) * pstride + c];
+        v[u][1] = partial[((int64_t)(r + u * FRL) * rstep * 2 + 1) * pstride + c];
+      }
+#pragma unroll
+      for (int u = 0; u < FUN; ++u) { a += (double)v[u][0]; b += (double)v[u][1]; }
     }
+    float t[FUN][2];                                  // the remainder, also fetched together
+#pragma unroll
+    for (int u = 0; u < FUN; ++u) {
+      const int rr = r + u * FRL;
+      const bool ok = rr < rows;
+      const int64_t q = (int64_t)(ok ? rr : 0) * rstep * 2 * pstride + c;
+      t[u][0] = ok ? partial[q] : 0.f;
+      t[u][1] = ok ? partial[q + pstride] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < FUN; ++u) { a += (double)t[u][0]; b += (double)t[u][1]; }
+  }
   sm[threadIdx.y][0][threadIdx.x] = a;
   sm[threadIdx.y][1][threadIdx.x] = b;
   __syncthreads();
-  s1 = sm[0][0][threadIdx.x] + sm[1][0][threadIdx.x] + sm[2][0][threadIdx.x] + sm[3][0][threadIdx.x];
-  s2 = sm[0][1][threadIdx.x] + sm[1][1][threadIdx.x] + sm[2][1][threadIdx.x] + sm[3][1][threadIdx.x];
+  s1 = s2 = 0.0;
+  if (threadIdx.y == 0)
+#pragma unroll 8
+    for (int y = 0; y < FRL; ++y) { s1 += sm[y][0][threadIdx.x]; s2 += sm[y][1][threadIdx.x]; }
 }
 
-__global__ void bn_finalize_train_kernel(const float* partial, int rows, int rstep, int C, int pstride, double count, const float* gamma,
+__global__ __launch_bounds__(FCW * FRL) void bn_finalize_train_kernel(const float* partial, int rows, int rstep, int C, int pstride, double count, const float* gamma,
                                          const float* beta, float eps, float momentum, float* running_mean,
                                          float* running_var, int64_t* nbt, float* mean, float* invstd, float* scale,
                                          float* shift) {
-  __shared__ double sm[4][2][64];
-  const int c = blockIdx.x * 64 + threadIdx.x;
+  __shared__ double sm[FRL][2][FCW];
+  const int c = blockIdx.x * FCW + threadIdx.x;
   double s1, s2;
   reduce_slab2(partial, rows, rstep, C, pstride, c, s1, s2, sm);
   if (threadIdx.y != 0 || c >= C) return;
@@ -102,11 +132,11 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
   shift[c] = fmaf(-rm[c], sc, b);
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* partial, int rows, int rstep, int C, int pstride, double count, const float* gamma,
+__global__ __launch_bounds__(FCW * FRL) void bn_bwd_finalize_kernel(const float* partial, int rows, int rstep, int C, int pstride, double count, const float* gamma,
                                        const float* mean, const float* invstd, int training, float* dgamma,
                                        float* dbeta, float* al, float* be, float* ga, float* dbias) {
-  __shared__ double sm[4][2][64];
-  const int c = blockIdx.x * 64 + threadIdx.x;
+  __shared__ double sm[FRL][2][FCW];
+  const int c = blockIdx.x * FCW + threadIdx.x;
   double s1, s2;
   reduce_slab2(partial, rows, rstep, C, pstride, c, s1, s2, sm);
   if (threadIdx.y != 0 || c >= C) return;
@@ -203,7 +233,7 @@ int kd_bn_finalize_train(float* partial, int rows, int C, int pstride, int64_t c
                          float* mean, float* invstd, float* scale, float* shift, void* stream) {
   KD_REQUIRE(partial && rows > 0 && C > 0 && pstride >= C && count > 0 && mean && invstd && scale && shift, KD_ERR_ARG, "kd_bn_finalize_train: bad args");
   const int rstep = slab_prereduce(partial, rows, C, pstride, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 63) / 64), dim3(64, 4), 0, (hipStream_t)stream, partial, rows,
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + FCW - 1) / FCW), dim3(FCW, FRL), 0, (hipStream_t)stream, partial, rows,
                      rstep, C, pstride, (double)count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd, scale,
                      shift);
   return kd_check_launch("kd_bn_finalize_train");
@@ -246,7 +276,7 @@ int kd_bn_bwd_finalize(float* partial, int rows, int C, int pstride, int64_t cou
                        float* ga, float* dbias, void* stream) {
   KD_REQUIRE(partial && rows > 0 && C > 0 && pstride >= C && count > 0 && mean && invstd && al && be && ga, KD_ERR_ARG, "kd_bn_bwd_finalize: bad args");
   const int rstep = slab_prereduce(partial, rows, C, pstride, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64, 4), 0, (hipStream_t)stream, partial, rows,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FCW - 1) / FCW), dim3(FCW, FRL), 0, (hipStream_t)stream, partial, rows,
                      rstep, C, pstride, (double)count, gamma, mean, invstd, training, dgamma, dbeta, al, be, ga, dbias);
   return kd_check_launch("kd_bn_bwd_finalize");
 }

@@ -99,7 +99,7 @@ struct DwArgs {
   const float* w;                                                 // [C][9]
   float* y; float* partial;                                       // raw out [B,Ho,Wo,C]; stats slab
   int B, H, W, C, Ho, Wo, stride;
-  int groups, slots;
+  int groups, slots, nchunk;     // channel quads per chunk, adjacent columns per block, channel chunks (dw_layout)
   int nt;                                                         // large output: non-temporal stores
 };
 
@@ -115,7 +115,7 @@ struct DwBwdArgs {
   float* gx; float* partial;           // data: G_x [B,H,W,C] (masked) + stats slab [grid][2][C]
   float* wslab;                        // weight: slab [grid][C*9]
   int B, H, W, C, Ho, Wo, stride;
-  int groups, slots;
+  int groups, slots, nchunk;     // channel quads per chunk, adjacent columns per block, channel chunks (dw_layout)
   int nt;                              // large gx: non-temporal stores
 };
 
@@ -185,16 +185,19 @@ __device__ __forceinline__ void dw_fma_row(float4& acc, const DwRow& r, const fl
   acc.w = fmaf(r.l.w, w[3][kh * 3], fmaf(r.c.w, w[3][kh * 3 + 1], fmaf(r.r.w, w[3][kh * 3 + 2], acc.w)));
 }
 
-__device__ __forceinline__ void dw_block_stats(float* red, float4 s1, float4 s2, float* partial, int C, int groups, int slots) {
+// one slab row per block ROW bx; a block owns the CW = 4 * groups channels from cbase (all of them when nchunk == 1)
+__device__ __forceinline__ void dw_block_stats(float* red, float4 s1, float4 s2, float* partial, int C, int groups, int slots, int bx,
+                                               int cbase) {
   const int tid = threadIdx.x;
   kd_st4(red + tid * 4, s1);
   kd_st4(red + 1024 + tid * 4, s2);
   __syncthreads();
-  for (int i = tid; i < 2 * C; i += 256) {
-    const int st = i / C, c = i % C;
+  const int CW = groups * 4;
+  for (int i = tid; i < 2 * CW; i += 256) {
+    const int st = i / CW, c = i % CW;
     float s = 0.f;
     for (int sl = 0; sl < slots; ++sl) s += red[st * 1024 + (sl * groups + c / 4) * 4 + (c & 3)];
-    partial[((int64_t)blockIdx.x * 2 + st) * C + c] = s;
+    partial[((int64_t)bx * 2 + st) * C + cbase + c] = s;
   }
 }
 
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(256) void dw_fwd_sw_kernel(DwArgs a) {
   const int tid = threadIdx.x;
   const int gidx = tid % a.groups, slot = tid / a.groups;
   const bool active = slot < a.slots;
-  const int c0 = gidx * 4;
+  const int bx = blockIdx.x / a.nchunk, nbx = gridDim.x / a.nchunk, cbase = (blockIdx.x % a.nchunk) * a.groups * 4;
+  const int c0 = cbase + gidx * 4;
   float wreg[4][9];
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4();
   float4 s1 = kd_zero4(), s2 = kd_zero4();
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void dw_fwd_sw_kernel(DwArgs a) {
     if (deferred) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
     const int nseg = (a.Ho + DW_SEG - 1) / DW_SEG;
     const int64_t items = (int64_t)a.B * nseg * a.Wo;
-    for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+    for (int64_t it = (int64_t)bx * a.slots + slot; it < items; it += (int64_t)nbx * a.slots) {
       const int wo = (int)(it % a.Wo), sg = (int)((it / a.Wo) % nseg), b = (int)(it / ((int64_t)a.Wo * nseg));
       const int h0 = sg * DW_SEG, h1 = h0 + DW_SEG < a.Ho ? h0 + DW_SEG : a.Ho;
       const int wi = wo * STRIDE;
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256) void dw_fwd_sw_kernel(DwArgs a) {
       }
     }
   }
-  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
+  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots, bx, cbase);
 }
 
 struct DwRaw { float4 d, y; };
@@ -287,7 +291,8 @@ __global__ __launch_bounds__(256) void dw_bwd_data_sw_kernel(DwBwdArgs a) {
   const int tid = threadIdx.x;
   const int gidx = tid % a.groups, slot = tid / a.groups;
   const bool active = slot < a.slots;
-  const int c0 = gidx * 4;
+  const int bx = blockIdx.x / a.nchunk, nbx = gridDim.x / a.nchunk, cbase = (blockIdx.x % a.nchunk) * a.groups * 4;
+  const int c0 = cbase + gidx * 4;
   float4 s1 = kd_zero4(), s2 = kd_zero4();
   if (active) {
     float wf[4][9];                     // flipped taps: wf[j][(dh+1)*3 + (dw+1)] = w[j][(1-dh)*3 + (1-dw)]
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_sw_kernel(DwBwdArgs a) {
     if (a.mean) { mean = kd_ld4(a.mean + c0); inv = kd_ld4(a.invstd + c0); }
     const int nseg = (a.H + DW_SEG - 1) / DW_SEG;
     const int64_t items = (int64_t)a.B * nseg * a.W;
-    for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+    for (int64_t it = (int64_t)bx * a.slots + slot; it < items; it += (int64_t)nbx * a.slots) {
       const int wi = (int)(it % a.W), sg = (int)((it / a.W) % nseg), b = (int)(it / ((int64_t)a.W * nseg));
       const int h0 = sg * DW_SEG, h1 = h0 + DW_SEG < a.H ? h0 + DW_SEG : a.H;
       DwRow r0 = dw_load_dy_row(a, al, be, ga, dsc, dsh, b, h0 - 1, wi, c0);
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_sw_kernel(DwBwdArgs a) {
       }
     }
   }
-  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
+  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots, bx, cbase);
 }
 
 // stride-1 data AND weight gradient in one pass (the separate kernels read the folded dy and the raw input twice: seven
@@ -358,7 +363,8 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
   const int tid = threadIdx.x;
   const int gidx = tid % a.groups, slot = tid / a.groups;
   const bool active = slot < a.slots;
-  const int c0 = gidx * 4;
+  const int bx = blockIdx.x / a.nchunk, nbx = gridDim.x / a.nchunk, cbase = (blockIdx.x % a.nchunk) * a.groups * 4;
+  const int c0 = cbase + gidx * 4;
   float4 s1 = kd_zero4(), s2 = kd_zero4();
   float4 wacc[9];
 #pragma unroll
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
     if (a.mean) { mean = kd_ld4(a.mean + c0); inv = kd_ld4(a.invstd + c0); }
     const int nseg = (a.H + DW_SEG - 1) / DW_SEG;
     const int64_t items = (int64_t)a.B * nseg * a.W;
-    for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+    for (int64_t it = (int64_t)bx * a.slots + slot; it < items; it += (int64_t)nbx * a.slots) {
       const int wi = (int)(it % a.W), sg = (int)((it / a.W) % nseg), b = (int)(it / ((int64_t)a.W * nseg));
       const int h0 = sg * DW_SEG, h1 = h0 + DW_SEG < a.H ? h0 + DW_SEG : a.H;
       DwRow r0 = dw_load_dy_row(a, al, be, ga, dsc, dsh, b, h0 - 1, wi, c0);
@@ -438,15 +444,15 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
       }
     }
   }
-  if (a.partial) { dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots); }
+  if (a.partial) { dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots, bx, cbase); }
   for (int t = 0; t < 9; ++t) {        // per-block weight-gradient partials, summed in fixed order by kd_slab_reduce
     __syncthreads();
     kd_st4(red + tid * 4, active ? wacc[t] : kd_zero4());
     __syncthreads();
-    for (int c = tid; c < a.C; c += 256) {
+    for (int c = tid; c < a.groups * 4; c += 256) {
       float s = 0.f;
       for (int sl = 0; sl < a.slots; ++sl) s += red[(sl * a.groups + c / 4) * 4 + (c & 3)];
-      a.wslab[(int64_t)blockIdx.x * a.C * 9 + c * 9 + t] = s;
+      a.wslab[(int64_t)bx * a.C * 9 + (cbase + c) * 9 + t] = s;
     }
   }
 }
@@ -621,7 +627,8 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(DwBwdArgs a) {
   const int tid = threadIdx.x;
   const int gidx = tid % a.groups, slot = tid / a.groups;
   const bool active = slot < a.slots;
-  const int c0 = gidx * 4;
+  const int bx = blockIdx.x / a.nchunk, nbx = gridDim.x / a.nchunk, cbase = (blockIdx.x % a.nchunk) * a.groups * 4;
+  const int c0 = cbase + gidx * 4;
   float4 s1 = kd_zero4(), s2 = kd_zero4();
   if (active) {
     float4 wt[9];                         // wt[t] = tap t of the thread's 4 channels
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(DwBwdArgs a) {
         xq[k] = kd_ld4(a.x + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0);
       }
     };
-    for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+    for (int64_t it = (int64_t)bx * a.slots + slot; it < items; it += (int64_t)nbx * a.slots) {
       const int q = (int)(it % QW), sg = (int)((it / QW) % nseg), b = (int)(it / ((int64_t)QW * nseg));
       const int a0 = sg * QSEG, a1 = a0 + QSEG < QH ? a0 + QSEG : QH;
       const bool w0ok = q < a.Wo, w1ok = q + 1 < a.Wo;
@@ -706,7 +713,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(DwBwdArgs a) {
       }
     }
   }
-  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
+  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots, bx, cbase);
 }
 
 // stride-2 data AND weight gradient in one pass over the same quads: the pairs (dy, input pixel) of the weight gradient
@@ -722,7 +729,8 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_s2_kernel(DwBwdArgs a) {
   const int tid = threadIdx.x;
   const int gidx = tid % a.groups, slot = tid / a.groups;
   const bool active = slot < a.slots;
-  const int c0 = gidx * 4;
+  const int bx = blockIdx.x / a.nchunk, nbx = gridDim.x / a.nchunk, cbase = (blockIdx.x % a.nchunk) * a.groups * 4;
+  const int c0 = cbase + gidx * 4;
   float4 s1 = kd_zero4(), s2 = kd_zero4();
   if (active) {
     float4 wt[9];                         // wt[t] = tap t of the thread's 4 channels
@@ -755,7 +763,7 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_s2_kernel(DwBwdArgs a) {
         xq[k] = kd_ld4(a.x + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0);
       }
     };
-    for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+    for (int64_t it = (int64_t)bx * a.slots + slot; it < items; it += (int64_t)nbx * a.slots) {
       const int q = (int)(it % QW), sg = (int)((it / QW) % nseg), b = (int)(it / ((int64_t)QW * nseg));
       const int a0 = sg * QSEG, a1 = a0 + QSEG < QH ? a0 + QSEG : QH;
       const bool w0ok = q < a.Wo, w1ok = q + 1 < a.Wo;
@@ -822,15 +830,15 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_s2_kernel(DwBwdArgs a) {
       }
     }
   }
-  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots);
+  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots, bx, cbase);
   for (int t = 0; t < 9; ++t) {        // per-block weight-gradient partials, summed in fixed order by kd_slab_reduce
     __syncthreads();
     kd_st4(red + tid * 4, active ? wacc[t] : kd_zero4());
     __syncthreads();
-    for (int c = tid; c < a.C; c += 256) {
+    for (int c = tid; c < a.groups * 4; c += 256) {
       float s = 0.f;
       for (int sl = 0; sl < a.slots; ++sl) s += red[(sl * a.groups + c / 4) * 4 + (c & 3)];
-      a.wslab[(int64_t)blockIdx.x * a.C * 9 + c * 9 + t] = s;
+      a.wslab[(int64_t)bx * a.C * 9 + (cbase + c) * 9 + t] = s;
     }
   }
 }
@@ -842,7 +850,8 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_sw_kernel(DwBwdArgs a) {
   const int tid = threadIdx.x;
   const int gidx = tid % a.groups, slot = tid / a.groups;
   const bool active = slot < a.slots;
-  const int c0 = gidx * 4;
+  const int bx = blockIdx.x / a.nchunk, nbx = gridDim.x / a.nchunk, cbase = (blockIdx.x % a.nchunk) * a.groups * 4;
+  const int c0 = cbase + gidx * 4;
   float4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = kd_zero4();
@@ -855,7 +864,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_sw_kernel(DwBwdArgs a) {
     if (deferred) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
     const int nseg = (a.Ho + DW_SEG - 1) / DW_SEG;
     const int64_t items = (int64_t)a.B * nseg * a.Wo;
-    for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
+    for (int64_t it = (int64_t)bx * a.slots + slot; it < items; it += (int64_t)nbx * a.slots) {
       const int wo = (int)(it % a.Wo), sg = (int)((it / a.Wo) % nseg), b = (int)(it / ((int64_t)a.Wo * nseg));
       const int h0 = sg * DW_SEG, h1 = h0 + DW_SEG < a.Ho ? h0 + DW_SEG : a.Ho;
       const int wi = wo * STRIDE;
@@ -893,10 +902,10 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_sw_kernel(DwBwdArgs a) {
     __syncthreads();
     kd_st4(red + tid * 4, acc[t]);
     __syncthreads();
-    for (int c = tid; c < a.C; c += 256) {
+    for (int c = tid; c < a.groups * 4; c += 256) {
       float s = 0.f;
       for (int sl = 0; sl < a.slots; ++sl) s += red[(sl * a.groups + c / 4) * 4 + (c & 3)];
-      a.wslab[(int64_t)blockIdx.x * a.C * 9 + c * 9 + t] = s;
+      a.wslab[(int64_t)bx * a.C * 9 + (cbase + c) * 9 + t] = s;
     }
   }
 }
@@ -915,6 +924,28 @@ static int kd_dw_fused_mode() {
     g_dw_mode.store(m, std::memory_order_relaxed);
   }
   return m;
+}
+
+// Thread layout of the column-walk kernels.  A block is 256 threads = `slots` adjacent image columns x `groups` channel quads
+// (float4 lanes).  Up to 64 quads one block spans all channels; wider tensors (C = 384 / 768: 96 / 192 quads left room for
+// two columns / one column per block, so the three-column windows of neighbouring columns were fetched by different
+// workgroups -- usually on different XCDs, i.e. through different L2s) are cut into chunks of 32 quads: 8 adjacent columns
+// per block again, their overlapping window loads served by the CU's own cache.  blockIdx = row * nchunk + chunk; a block
+// ROW owns one statistics / weight-gradient slab row (every chunk writes its own channel range of it).
+struct DwLayout { int groups, slots, nchunk, rows, grid; };
+static DwLayout dw_layout(int64_t npix, int C) {
+  DwLayout l;
+  const int quads = C / 4;
+  l.nchunk = (quads > 64 && quads % 32 == 0) ? quads / 32 : 1;
+  l.groups = quads / l.nchunk;
+  l.slots = 256 / l.groups;
+  if (l.slots < 1) l.slots = 1;
+  const int64_t need = (npix + l.slots - 1) / l.slots;
+  const int cap = 2048 / l.nchunk;
+  l.rows = (int)(need < cap ? need : cap);
+  if (l.rows < 1) l.rows = 1;
+  l.grid = l.rows * l.nchunk;
+  return l;
 }
 
 extern "C" {
@@ -946,7 +977,7 @@ int kd_stem_im2col(const float* x_nchw, float* col, int B, int Cin, int H, int W
   return kd_check_launch("kd_stem_im2col");
 }
 
-int64_t kd_dwconv_stat_rows(int64_t npix, int C) { return kd_cg_layout(npix, C).grid; }
+int64_t kd_dwconv_stat_rows(int64_t npix, int C) { return dw_layout(npix, C).rows; }
 
 int kd_dwconv3x3_fwd(const float* x, const float* sc, const float* sh, int act, const float* w, float* y,
                      float* partial, int B, int H, int W, int C, int stride, void* stream) {
@@ -954,8 +985,8 @@ int kd_dwconv3x3_fwd(const float* x, const float* sc, const float* sh, int act, 
   KD_REQUIRE(C % 4 == 0 && C <= 1024 && (stride == 1 || stride == 2), KD_ERR_SHAPE, "kd_dwconv3x3_fwd: C=%d stride=%d unsupported", C, stride);
   KD_REQUIRE(kd_aligned16(x) && kd_aligned16(y), KD_ERR_ALIGN, "kd_dwconv3x3_fwd: alignment");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-  const KdCgLayout l = kd_cg_layout((int64_t)B * Ho * Wo, C);
-  DwArgs a{x, sc, sh, act, w, y, partial, B, H, W, C, Ho, Wo, stride, l.groups, l.slots,
+  const DwLayout l = dw_layout((int64_t)B * Ho * Wo, C);
+  DwArgs a{x, sc, sh, act, w, y, partial, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk,
            kd_nt_store((size_t)B * Ho * Wo * C * sizeof(float))};
   if (stride == 1) hipLaunchKernelGGL(dw_fwd_sw_kernel<1>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(dw_fwd_sw_kernel<2>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -964,7 +995,7 @@ int kd_dwconv3x3_fwd(const float* x, const float* sc, const float* sh, int act, 
 
 // (one slab row per workgroup; the fused stride-2 kernel is launched over the INPUT pixels: at most 4 per output pixel)
 size_t kd_dwconv_bwd_ws_bytes(int64_t npix_out, int C) {
-  return (size_t)kd_cg_layout(4 * npix_out, C).grid * (size_t)C * 9 * sizeof(float);
+  return (size_t)dw_layout(4 * npix_out, C).rows * (size_t)C * 9 * sizeof(float);
 }
 
 // Backward of y = dwconv3x3(act(x*sc+sh)).  (D, Y, al, be, ga[, dsc, dsh, d_act]) describe dL/dy_raw;
@@ -980,55 +1011,58 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
   int dw_mode = kd_dw_fused_mode();
-  if (dw_mode == 3) dw_mode = (C >= 384 && W >= 64) ? 2 : 1;
+  // by shape (tools/bench_dw at 256 frames, round 3, with the channel-chunked column walk): the tile form wins on every
+  // stride-1 shape of the step from 64 channels up (64: 283 vs 323 us, 128: 523 vs 573, 256: 968 vs 1054, 384: 1319 vs 1500, 768 at 32 x 32:
+  // 695 vs 784); below a 64-channel chunk it idles lanes (32 channels: 810 vs 575)
+  if (dw_mode == 3) dw_mode = (C >= 64 && C % 64 == 0 && W >= 16) ? 2 : 1;
   if (gx && dw && stride == 1 && dw_mode != 0) {               // one pass: data gradient + statistics + weight-gradient partials
-    const KdCgLayout l = kd_cg_layout((int64_t)B * H * W, C);
-    KD_REQUIRE(ws && ws_bytes >= (size_t)l.grid * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
+    const DwLayout l = dw_layout((int64_t)B * H * W, C);
+    KD_REQUIRE(ws && ws_bytes >= (size_t)l.rows * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,
-                (float*)ws, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
-    if (dw_mode == 2) {                     // tile form: l.grid slab rows (the row count the callers sized their slabs for) x channel chunks
+                (float*)ws, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
+    if (dw_mode == 2) {                     // tile form: l.rows slab rows (the row count the callers sized their slabs for) x channel chunks
       const int nchunk = (C + DT_CQ * 4 - 1) / (DT_CQ * 4);
-      hipLaunchKernelGGL(dw_bwd_tile_s1_kernel, dim3((unsigned)l.grid * nchunk), dim3(256), 0, st, a, l.grid, nchunk);
+      hipLaunchKernelGGL(dw_bwd_tile_s1_kernel, dim3((unsigned)l.rows * nchunk), dim3(256), 0, st, a, l.rows, nchunk);
     } else
     hipLaunchKernelGGL(dw_bwd_fused_s1_kernel, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(fused)");
     if (rc) return rc;
-    return kd_slab_reduce_launch((const float*)ws, l.grid, (int64_t)C * 9, dw, st);
+    return kd_slab_reduce_launch((const float*)ws, l.rows, (int64_t)C * 9, dw, st);
   }
   if (gx && dw && stride == 2 && dw_mode != 0) {               // stride 2: the same fusion over 2x2 input quads
-    const KdCgLayout l = kd_cg_layout((int64_t)B * H * W, C);
-    KD_REQUIRE(ws && ws_bytes >= (size_t)l.grid * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
+    const DwLayout l = dw_layout((int64_t)B * H * W, C);
+    KD_REQUIRE(ws && ws_bytes >= (size_t)l.rows * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,
-                (float*)ws, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
+                (float*)ws, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
     hipLaunchKernelGGL(dw_bwd_fused_s2_kernel, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(fused, stride 2)");
     if (rc) return rc;
-    return kd_slab_reduce_launch((const float*)ws, l.grid, (int64_t)C * 9, dw, st);
+    return kd_slab_reduce_launch((const float*)ws, l.rows, (int64_t)C * 9, dw, st);
   }
   if (gx) {
-    const KdCgLayout l = kd_cg_layout((int64_t)B * H * W, C);
+    const DwLayout l = dw_layout((int64_t)B * H * W, C);
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,
-                nullptr, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
+                nullptr, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
     if (stride == 1) hipLaunchKernelGGL(dw_bwd_data_sw_kernel, dim3(l.grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dw_bwd_data_s2_kernel, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(data)");
     if (rc) return rc;
   }
   if (dw) {
-    const KdCgLayout l = kd_cg_layout((int64_t)B * Ho * Wo, C);
-    KD_REQUIRE(ws && ws_bytes >= (size_t)l.grid * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
+    const DwLayout l = dw_layout((int64_t)B * Ho * Wo, C);
+    KD_REQUIRE(ws && ws_bytes >= (size_t)l.rows * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, nullptr, nullptr, (float*)ws,
-                B, H, W, C, Ho, Wo, stride, l.groups, l.slots, 0};
+                B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk, 0};
     if (stride == 1) hipLaunchKernelGGL(dw_bwd_weight_sw_kernel<1>, dim3(l.grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dw_bwd_weight_sw_kernel<2>, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(weight)");
     if (rc) return rc;
-    return kd_slab_reduce_launch((const float*)ws, l.grid, (int64_t)C * 9, dw, st);
+    return kd_slab_reduce_launch((const float*)ws, l.rows, (int64_t)C * 9, dw, st);
   }
   return KD_OK;
 }
 
-int64_t kd_dwconv_bwd_stat_rows(int64_t npix_in, int C) { return kd_cg_layout(npix_in, C).grid; }
+int64_t kd_dwconv_bwd_stat_rows(int64_t npix_in, int C) { return dw_layout(npix_in, C).rows; }
 
 // 0 separate kernels, 1 fused column walk, 2 fused tile form, 3 choose by shape (default); returns the previous mode
 int kd_set_dw_bwd_mode(int mode) { (void)kd_dw_fused_mode(); return g_dw_mode.exchange(mode < 0 ? 0 : (mode > 3 ? 3 : mode)); }

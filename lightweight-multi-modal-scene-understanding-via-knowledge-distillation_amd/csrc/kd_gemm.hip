@@ -827,6 +827,17 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
   if (i < R * Cc) out[(int64_t)(i % Cc) * R + i / Cc] = in[i];
 }
 
+// every weight of a model in one launch: table[i] = {in, out, R, Cc, first block}; a block looks its matrix up by block index
+__global__ void transpose_batch_kernel(const int64_t* __restrict__ table, int n) {
+  int m = 0;
+  while (m + 1 < n && (int64_t)blockIdx.x >= table[(m + 1) * 5 + 4]) ++m;
+  const float* in = reinterpret_cast<const float*>(table[m * 5]);
+  float* out = reinterpret_cast<float*>(table[m * 5 + 1]);
+  const int R = (int)table[m * 5 + 2], Cc = (int)table[m * 5 + 3];
+  const int i = ((int)blockIdx.x - (int)table[m * 5 + 4]) * 256 + threadIdx.x;
+  if (i < R * Cc) out[(int64_t)(i % Cc) * R + i / Cc] = in[i];
+}
+
 template <int WN, int WK, int WM, bool SPLIT>
 int launch_wgrad(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
   constexpr int TN = 64 * WN, TK = 64 * WK, CH = SPLIT ? 16 * WM * (WM == 1 ? 2 : 1) : 32 * WM;
@@ -1137,6 +1148,14 @@ int kd_transpose(const float* in, float* out, int R, int Cc, void* stream) {
   KD_REQUIRE(in && out && R > 0 && Cc > 0, KD_ERR_ARG, "kd_transpose: bad args");
   hipLaunchKernelGGL(transpose_kernel, dim3((R * Cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, out, R, Cc);
   return kd_check_launch("kd_transpose");
+}
+
+// kd_transpose for n matrices at once.  table: device int64 [n][5] = {in pointer, out pointer, R, Cc, index of the matrix's first
+// 256-element block}, first-block indices ascending from 0; nblocks = their total (every matrix owns ceil(R*Cc/256) blocks).
+int kd_transpose_batch(const int64_t* table, int n, int nblocks, void* stream) {
+  KD_REQUIRE(table && n > 0 && nblocks >= n, KD_ERR_ARG, "kd_transpose_batch: bad args");
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, table, n);
+  return kd_check_launch("kd_transpose_batch");
 }
 
 }  // extern "C"

@@ -33,7 +33,10 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 constexpr int IW = 8;                       // waves per workgroup (two per SIMD share the resident weights)
 constexpr int K0 = 64, N1 = 128, N2 = 128;  // layer widths (lidar_encoder.py:26-34)
 constexpr int W1PL = N1 * K0, W2PL = N2 * N1;                         // bf16 per plane
-constexpr size_t LI_LDS = (size_t)3 * (W1PL + W2PL) * 2 + (size_t)(7 * K0 + 3 * N1) * 4;     // 147,456 + 3,328 B
+// NP = 3: the fp32-grade split arithmetic (three bf16 planes per operand, six piece products); NP = 1: the bf16-storage inference
+// mode (kdrt/bf16.py) -- operands rounded to bf16 once, one product, fp32 accumulation: what kd_bf16_pwconv computes, minus the
+// bf16 [points, 128] layer-1 tensor in HBM
+template <int NP> constexpr size_t li_lds() { return (size_t)NP * (W1PL + W2PL) * 2 + (size_t)(7 * K0 + 3 * N1) * 4; }   // 147,456 / 49,152 + 3,328 B
 
 struct LiArgs {
   const float* pts;                         // [P, 4] (compacted / cell-sorted in-range points first)
@@ -49,11 +52,12 @@ struct LiArgs {
 // 16-byte chunk swizzle of a weight row of CPR chunks (as kd_gemm_stream_kernel.h): conflict-free ds_read_b128
 template <int CPR> __device__ __forceinline__ int li_key(int n) { return CPR % 16 == 0 ? (n & 15) : ((n >> 1) & 7); }
 
+template <int NP>
 __global__ __launch_bounds__(64 * IW, 1) void lidar_mlp_scatter_infer_kernel(LiArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned short* W1h = reinterpret_cast<unsigned short*>(smem_raw);            // [3][128][64] bf16, swizzled
-  unsigned short* W2h = W1h + 3 * W1PL;                                          // [3][128][128] bf16, columns renumbered, swizzled
-  float* T0 = reinterpret_cast<float*>(W2h + 3 * W2PL);                          // [7][64]: w0.x .y .z .w, b0, sc0, sh0
+  unsigned short* W1h = reinterpret_cast<unsigned short*>(smem_raw);            // [NP][128][64] bf16, swizzled
+  unsigned short* W2h = W1h + NP * W1PL;                                         // [NP][128][128] bf16, columns renumbered, swizzled
+  float* T0 = reinterpret_cast<float*>(W2h + NP * W2PL);                         // [7][64]: w0.x .y .z .w, b0, sc0, sh0
   float* T1 = T0 + 7 * K0;                                                       // [3][128]: bias1, sc1, sh1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -65,8 +69,7 @@ __global__ __launch_bounds__(64 * IW, 1) void lidar_mlp_scatter_infer_kernel(LiA
     kd_split3(kd_ld4(g.W1 + n * K0 + 4 * k4), hi, mid, lo);
     unsigned short* d = W1h + n * K0 + ((k4 >> 1) ^ li_key<K0 / 8>(n)) * 8 + (k4 & 1) * 4;
     *reinterpret_cast<uint2*>(d) = hi;
-    *reinterpret_cast<uint2*>(d + W1PL) = mid;
-    *reinterpret_cast<uint2*>(d + 2 * W1PL) = lo;
+    if (NP == 3) { *reinterpret_cast<uint2*>(d + W1PL) = mid; *reinterpret_cast<uint2*>(d + 2 * W1PL) = lo; }
   }
   for (int i = tid; i < N2 * N1 / 4; i += 64 * IW) {
     const int n = i / (N1 / 4), q4 = i % (N1 / 4);                    // q4: group of 4 consecutive renumbered positions k' = 4 q4 ..
@@ -76,8 +79,7 @@ __global__ __launch_bounds__(64 * IW, 1) void lidar_mlp_scatter_infer_kernel(LiA
     kd_split3(kd_ld4(g.W2 + n * N1 + ch), hi, mid, lo);
     unsigned short* d = W2h + n * N1 + ((q4 >> 1) ^ li_key<N1 / 8>(n)) * 8 + (q4 & 1) * 4;
     *reinterpret_cast<uint2*>(d) = hi;
-    *reinterpret_cast<uint2*>(d + W2PL) = mid;
-    *reinterpret_cast<uint2*>(d + 2 * W2PL) = lo;
+    if (NP == 3) { *reinterpret_cast<uint2*>(d + W2PL) = mid; *reinterpret_cast<uint2*>(d + 2 * W2PL) = lo; }
   }
   for (int k = tid; k < K0; k += 64 * IW) {
     const float4 w = kd_ld4(g.w0 + 4 * k);
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(64 * IW, 1) void lidar_mlp_scatter_infer_kernel(LiA
 #pragma unroll
   for (int j = 0; j < 4; ++j) { const int c = 32 * j + r; eb[j] = g.bias2 ? g.bias2[c] : 0.f; es[j] = g.sc2[c]; eh[j] = g.sh2[c]; }
   const int f1 = h ^ li_key<K0 / 8>(r), f2 = h ^ li_key<N1 / 8>(r);      // physical chunk of k-step u = (2u) ^ f
-  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // (activation plane, weight plane), smallest terms first
+  constexpr int NX = NP == 3 ? 6 : 1;                                     // piece products per product
+  constexpr int PA[6] = {NP == 3 ? 0 : 0, 2, 1, 0, 1, 0}, PB[6] = {NP == 3 ? 2 : 0, 0, 1, 1, 0, 0};  // (activation plane, weight plane), smallest terms first
   unsigned* ugrid = reinterpret_cast<unsigned*>(g.grid);
 
   for (int s = wid; s < nslab; s += wtot) {
@@ -148,9 +151,9 @@ __global__ __launch_bounds__(64 * IW, 1) void lidar_mlp_scatter_infer_kernel(LiA
         const unsigned short* wp = W1p + (32 * t + r) * K0 + ((2 * u) ^ f1) * 8;
         bf16x8 ap[3];
 #pragma unroll
-        for (int pl2 = 0; pl2 < 3; ++pl2) ap[pl2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wp + pl2 * W1PL));
+        for (int pl2 = 0; pl2 < NP; ++pl2) ap[pl2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wp + pl2 * W1PL));
 #pragma unroll
-        for (int x = 0; x < 6; ++x)      // (weight plane PB, activation plane PA): the same six products in the same order as kd_lidar_l1_fwd
+        for (int x = 0; x < NX; ++x)     // (weight plane PB, activation plane PA): the same six products in the same order as kd_lidar_l1_fwd
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PB[x]], bp[PA[x]], acc[t], 0, 0, 0);
       }
     }
@@ -192,9 +195,9 @@ __global__ __launch_bounds__(64 * IW, 1) void lidar_mlp_scatter_infer_kernel(LiA
         const unsigned short* wp = W2p + (32 * j + r) * N1 + ((2 * sk) ^ f2) * 8;
         bf16x8 bp[3];
 #pragma unroll
-        for (int pl2 = 0; pl2 < 3; ++pl2) bp[pl2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wp + pl2 * W2PL));
+        for (int pl2 = 0; pl2 < NP; ++pl2) bp[pl2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wp + pl2 * W2PL));
 #pragma unroll
-        for (int x = 0; x < 6; ++x) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[sk][PA[x]], bp[PB[x]], acc[j], 0, 0, 0);
+        for (int x = 0; x < NX; ++x) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[sk][PA[x]], bp[PB[x]], acc[j], 0, 0, 0);
       }
 
     // ---- epilogue: BN2 + ReLU, running maximum over the lane's rows of one cell, atomicMax at cell boundaries ------------------
@@ -224,28 +227,54 @@ int kd_lidar_mlp_scatter_infer_supported(int C0, int C1, int C2) { return kd_gem
 // Eval-mode point MLP + BEV scatter-max in one kernel (see the head of this file).  All three activations are ReLU; sc* / sh*
 // are the eval BatchNorm coefficients (kd_bn_eval_coeffs); pts are the compacted in-range points with their grid rows in
 // `cell` (< 0: skip), p_dev an optional device-side count; grid [ncells][128] is zeroed here.
+static int li_launch(int np, const char* who, const float* pts, const int* cell, const int* p_dev, const float* w0, const float* b0,
+                     const float* sc0, const float* sh0, const float* W1, const float* bias1, const float* sc1, const float* sh1,
+                     const float* W2, const float* bias2, const float* sc2, const float* sh2, float* grid, int64_t ncells, int64_t P,
+                     void* stream) {
+  KD_REQUIRE(pts && cell && w0 && b0 && sc0 && sh0 && W1 && sc1 && sh1 && W2 && sc2 && sh2 && grid && ncells > 0 && P > 0, KD_ERR_ARG,
+             "%s: bad args", who);
+  KD_REQUIRE(P < (int64_t)1 << 31, KD_ERR_SHAPE, "%s: too many points", who);
+  KD_REQUIRE(kd_aligned16(pts) && kd_aligned16(w0) && kd_aligned16(W1) && kd_aligned16(W2), KD_ERR_ALIGN, "%s: 16-byte alignment", who);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(grid, 0, (size_t)ncells * N2 * sizeof(float), st);
+  KD_REQUIRE(e == hipSuccess, (int)e, "%s: memset failed: %s", who, hipGetErrorString(e));
+  const int64_t nslab = (P + 31) / 32, want = (nslab + IW - 1) / IW;
+  LiArgs g{pts, cell, p_dev, w0, b0, sc0, sh0, W1, bias1, sc1, sh1, W2, bias2, sc2, sh2, grid, (int)P};
+  if (np == 3) {
+    static std::atomic<uint64_t> raised3{0};
+    e = kd_raise_dynamic_lds((const void*)lidar_mlp_scatter_infer_kernel<3>, li_lds<3>(), raised3);
+    KD_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise the dynamic LDS limit to %zu B: %s", who, li_lds<3>(), hipGetErrorString(e));
+    hipLaunchKernelGGL(lidar_mlp_scatter_infer_kernel<3>, dim3((int)(want < 256 ? want : 256)), dim3(64 * IW), li_lds<3>(), st, g);
+  } else {
+    static std::atomic<uint64_t> raised1{0};
+    e = kd_raise_dynamic_lds((const void*)lidar_mlp_scatter_infer_kernel<1>, li_lds<1>(), raised1);
+    KD_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise the dynamic LDS limit to %zu B: %s", who, li_lds<1>(), hipGetErrorString(e));
+    hipLaunchKernelGGL(lidar_mlp_scatter_infer_kernel<1>, dim3((int)(want < 256 ? want : 256)), dim3(64 * IW), li_lds<1>(), st, g);
+  }
+  return kd_check_launch(who);
+}
+
 int kd_lidar_mlp_scatter_infer(const float* pts, const int* cell, const int* p_dev, const float* w0, const float* b0,
                                const float* sc0, const float* sh0, const float* W1, const float* bias1, const float* sc1,
                                const float* sh1, const float* W2, const float* bias2, const float* sc2, const float* sh2,
                                float* grid, int64_t ncells, int64_t P, int C0, int C1, int C2, void* stream) {
-  KD_REQUIRE(pts && cell && w0 && b0 && sc0 && sh0 && W1 && sc1 && sh1 && W2 && sc2 && sh2 && grid && ncells > 0 && P > 0, KD_ERR_ARG,
-             "kd_lidar_mlp_scatter_infer: bad args");
   KD_REQUIRE(kd_lidar_mlp_scatter_infer_supported(C0, C1, C2), KD_ERR_SHAPE,
              "kd_lidar_mlp_scatter_infer: no instance for widths %d / %d / %d in the %s arithmetic", C0, C1, C2,
              kd_gemm_split_mode() ? "split" : "exact-fp32");
-  KD_REQUIRE(P < (int64_t)1 << 31, KD_ERR_SHAPE, "kd_lidar_mlp_scatter_infer: too many points");
-  KD_REQUIRE(kd_aligned16(pts) && kd_aligned16(w0) && kd_aligned16(W1) && kd_aligned16(W2), KD_ERR_ALIGN, "kd_lidar_mlp_scatter_infer: 16-byte alignment");
-  hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grid, 0, (size_t)ncells * C2 * sizeof(float), st);
-  KD_REQUIRE(e == hipSuccess, (int)e, "kd_lidar_mlp_scatter_infer: memset failed: %s", hipGetErrorString(e));
-  static std::atomic<uint64_t> lds_raised{0};
-  e = kd_raise_dynamic_lds((const void*)lidar_mlp_scatter_infer_kernel, LI_LDS, lds_raised);
-  KD_REQUIRE(e == hipSuccess, (int)e, "kd_lidar_mlp_scatter_infer: cannot raise the dynamic LDS limit to %zu B: %s", LI_LDS, hipGetErrorString(e));
-  const int64_t nslab = (P + 31) / 32, want = (nslab + IW - 1) / IW;
-  const int grid_x = (int)(want < 256 ? want : 256);
-  LiArgs g{pts, cell, p_dev, w0, b0, sc0, sh0, W1, bias1, sc1, sh1, W2, bias2, sc2, sh2, grid, (int)P};
-  hipLaunchKernelGGL(lidar_mlp_scatter_infer_kernel, dim3(grid_x), dim3(64 * IW), LI_LDS, st, g);
-  return kd_check_launch("kd_lidar_mlp_scatter_infer");
+  return li_launch(3, "kd_lidar_mlp_scatter_infer", pts, cell, p_dev, w0, b0, sc0, sh0, W1, bias1, sc1, sh1, W2, bias2, sc2, sh2, grid, ncells, P,
+                   stream);
+}
+
+// The same encoder in the bf16-storage inference mode (kdrt/bf16.py): operands rounded to bf16, one MFMA product per element,
+// fp32 accumulation, fp32 grid -- kd_bf16_pwconv(a_kind 3) + kd_bf16_pwconv(epi 4) without the bf16 [points, 128] tensor between them.
+int kd_bf16_lidar_mlp_scatter_supported(int C0, int C1, int C2) { return C0 == K0 && C1 == N1 && C2 == N2; }
+int kd_bf16_lidar_mlp_scatter(const float* pts, const int* cell, const int* p_dev, const float* w0, const float* b0,
+                              const float* sc0, const float* sh0, const float* W1, const float* bias1, const float* sc1,
+                              const float* sh1, const float* W2, const float* bias2, const float* sc2, const float* sh2,
+                              float* grid, int64_t ncells, int64_t P, int C0, int C1, int C2, void* stream) {
+  KD_REQUIRE(kd_bf16_lidar_mlp_scatter_supported(C0, C1, C2), KD_ERR_SHAPE, "kd_bf16_lidar_mlp_scatter: no instance for widths %d / %d / %d", C0, C1, C2);
+  return li_launch(1, "kd_bf16_lidar_mlp_scatter", pts, cell, p_dev, w0, b0, sc0, sh0, W1, bias1, sc1, sh1, W2, bias2, sc2, sh2, grid, ncells, P,
+                   stream);
 }
 
 }  // extern "C"

@@ -132,6 +132,15 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* a, const float* b
   if (threadIdx.x == 0 && slab) slab[blockIdx.x] = sh3[0];
 }
 
+// total = ce + ckl * kl + beta * (mse_c + mse_l), rounded after every operation like the fp32 tensor expression it replaces
+__global__ void kd_total_kernel(const float* ce_kl, const float* mse_c, const float* mse_l, float ckl, float beta, float* total) {
+  if (threadIdx.x == 0) {
+    const float t = __fadd_rn(ce_kl[0], __fmul_rn(ckl, ce_kl[1]));
+    const float m = __fadd_rn(mse_c ? mse_c[0] : 0.f, mse_l ? mse_l[0] : 0.f);
+    total[0] = __fadd_rn(t, __fmul_rn(beta, m));
+  }
+}
+
 __global__ void mse_final_kernel(const float* slab, int nblk, double n, float* loss) {
   __shared__ double red[256];
   double s = 0.0;
@@ -231,6 +240,14 @@ int kd_mse_fwd_bwd(const float* a, const float* b, int64_t n, float gcoef, const
                      loss ? (float*)ws : nullptr);
   if (loss) hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, (int)grid, (double)n, loss);
   return kd_check_launch("kd_mse_fwd_bwd");
+}
+
+// The KD objective's value from its parts: total = ce_kl[0] + ckl * ce_kl[1] + beta * (mse_c + mse_l),
+// each operation rounded to fp32 in this order (what `ce + (alpha*T*T) * kl + beta * (mse_c + mse_l)` on fp32 scalars gives).
+int kd_kd_total(const float* ce_kl, const float* mse_c, const float* mse_l, float ckl, float beta, float* total, void* stream) {
+  KD_REQUIRE(ce_kl && total, KD_ERR_ARG, "kd_kd_total: bad args");
+  hipLaunchKernelGGL(kd_total_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ce_kl, mse_c, mse_l, ckl, beta, total);
+  return kd_check_launch("kd_kd_total");
 }
 
 // conf[NC*NC] (uint64, ACCUMULATED into) and/or pred[B*HW] (int64 argmax over the class dim).

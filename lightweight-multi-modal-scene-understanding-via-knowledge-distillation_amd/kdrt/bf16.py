@@ -21,6 +21,11 @@ from .lib import KDError, lib
 from .ops import ACT_RELU, ACT_RELU6, P, stream
 
 
+import os as _os
+
+_LIDAR_ONE_KERNEL = _os.environ.get("KD_BF16_LIDAR_ONE_KERNEL", "1") != "0"
+
+
 def _coef(spec):
     C = spec.bn.running_mean.numel()
     return units._coeffs(spec, None, 0, C, 0, False, None, spec.bn.running_mean.device)
@@ -44,8 +49,10 @@ def _pw(x, spec, M, res=None, out=None, a_kind=0, m_dev=None):
     bnc = _coef(spec)
     if out is None:
         out = torch.empty(M, N, device=w.device, dtype=torch.bfloat16)
+    e0 = ops._prof_begin()
     lib.call("kd_bf16_pwconv", P(x), x.stride(0), a_kind, P(w), P(b), P(bnc.scale), P(bnc.shift), spec.act, P(out), out.stride(0),
              P(res), res.stride(0) if res is not None else 0, 0, M, K, N, P(m_dev), None, None, None, None, 0, None, None, 0, stream())
+    ops._prof_end(e0, "bf16_pw", 2.0 * M * N * K, M * K * (4.0 if a_kind == 1 else 2.0) + M * N * (4.0 if res is not None else 2.0) + 4.0 * N * K)
     return out
 
 
@@ -56,7 +63,9 @@ def _dw(x, spec, geom):
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
     bnc = _coef(spec)
     y = torch.empty(B * Ho * Wo, C, device=x.device, dtype=torch.bfloat16)
+    e0 = ops._prof_begin()
     lib.call("kd_bf16_dwconv3x3", P(x), P(spec.conv.weight), P(bnc.scale), P(bnc.shift), spec.act, P(y), B, H, W, C, s, stream())
+    ops._prof_end(e0, "bf16_dw", 18.0 * B * Ho * Wo * C, 2.0 * C * B * (H * W + Ho * Wo) + 36.0 * C)
     return y, (B, Ho, Wo)
 
 
@@ -95,7 +104,9 @@ def forward_bf16(model, images: torch.Tensor, points: torch.Tensor, return_inter
     bnc = _coef(stem)
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     x = torch.empty(B * Ho * Wo, 32, device=dev, dtype=torch.bfloat16)
+    e0 = ops._prof_begin()
     lib.call("kd_bf16_stem", P(img), P(enc.stem[0].weight), P(bnc.scale), P(bnc.shift), ACT_RELU6, P(x), B, Cin, H, W, 32, stream())
+    ops._prof_end(e0, "bf16_stem", 2.0 * B * Ho * Wo * 32 * Cin * 9, 4.0 * B * Cin * H * W + 2.0 * B * Ho * Wo * 32)
     geom = (B, Ho, Wo)
     feats = {}
     for name in ("stage1", "stage2", "stage3", "stage4", "stage5"):
@@ -114,8 +125,10 @@ def forward_bf16(model, images: torch.Tensor, points: torch.Tensor, return_inter
     Ct = lats[0][0].shape[1]
     fused = torch.empty(B * Hm * Wm, Ct, device=dev, dtype=torch.bfloat16)
     a = [(P(t), g[1], g[2]) for t, g in lats] + [(None, 0, 0)] * (3 - len(lats))
+    e0 = ops._prof_begin()
     lib.call("kd_bf16_bilinear_sum", a[0][0], a[0][1], a[0][2], a[1][0], a[1][1], a[1][2], a[2][0], a[2][1], a[2][2], P(fused), B, Hm, Wm, Ct,
              stream())
+    ops._prof_end(e0, "bf16_resize_sum", 0.0, 2.0 * Ct * (sum(t.shape[0] for t, _ in lats) + B * Hm * Wm))
     cam, cgeom = _chain(fused, (B, Hm, Wm), fpn.post.units())
     # ---- LiDAR encoder (lidar_encoder.py:57-99): points sorted by cell, layer 0 recomputed inside the layer-1 GEMM, layer 2
     # scatter-maxes straight into the fp32 BEV grid (the [points, 128] layer outputs exist only as bf16 / not at all) ----------
@@ -133,12 +146,26 @@ def forward_bf16(model, images: torch.Tensor, points: torch.Tensor, return_inter
     c0, c1, c2 = _coef(u0), _coef(u1), _coef(u2)
     Mp = Bp * Np
     K0, N1, N2 = u0.conv.weight.shape[0], u1.conv.weight.shape[0], u2.conv.weight.shape[0]
-    y1 = torch.empty(Mp, N1, device=dev, dtype=torch.bfloat16)
-    lib.call("kd_bf16_pwconv", P(spts), 4, 3, P(u1.conv.weight), P(u1.conv.bias), P(c1.scale), P(c1.shift), u1.act, P(y1), N1, None, 0, 0,
-             Mp, K0, N1, P(counter), P(u0.conv.weight), P(u0.conv.bias), P(c0.scale), P(c0.shift), u0.act, None, None, 0, stream())
-    grid = torch.zeros(Bp * Hg * Wg, N2, device=dev, dtype=torch.float32)
-    lib.call("kd_bf16_pwconv", P(y1), N1, 0, P(u2.conv.weight), P(u2.conv.bias), P(c2.scale), P(c2.shift), u2.act, None, 0, None, 0, 4,
-             Mp, N1, N2, P(counter), None, None, None, None, 0, P(cell), P(grid), N2, stream())
+    all_relu = u0.act == ACT_RELU and u1.act == ACT_RELU and u2.act == ACT_RELU
+    if _LIDAR_ONE_KERNEL and all_relu and lib.kd_bf16_lidar_mlp_scatter_supported(K0, N1, N2):
+        # the whole point MLP + scatter-max in one kernel: no [points, 128] tensor in HBM at all (csrc/kd_lidar_infer.hip, NP = 1)
+        grid = torch.empty(Bp * Hg * Wg, N2, device=dev, dtype=torch.float32)          # zeroed by the call
+        e0 = ops._prof_begin()
+        lib.call("kd_bf16_lidar_mlp_scatter", P(spts), P(cell), P(counter), P(u0.conv.weight), P(u0.conv.bias), P(c0.scale), P(c0.shift),
+                 P(u1.conv.weight), P(u1.conv.bias), P(c1.scale), P(c1.shift), P(u2.conv.weight), P(u2.conv.bias), P(c2.scale), P(c2.shift),
+                 P(grid), Bp * Hg * Wg, Mp, K0, N1, N2, stream())
+        ops._prof_end(e0, "bf16_lidar", 2.0 * Mp * (K0 * N1 + N1 * N2), 20.0 * Mp + 4.0 * (K0 * N1 + N1 * N2), counter, Mp)
+    else:
+        y1 = torch.empty(Mp, N1, device=dev, dtype=torch.bfloat16)
+        e0 = ops._prof_begin()
+        lib.call("kd_bf16_pwconv", P(spts), 4, 3, P(u1.conv.weight), P(u1.conv.bias), P(c1.scale), P(c1.shift), u1.act, P(y1), N1, None, 0, 0,
+                 Mp, K0, N1, P(counter), P(u0.conv.weight), P(u0.conv.bias), P(c0.scale), P(c0.shift), u0.act, None, None, 0, stream())
+        ops._prof_end(e0, "bf16_pw", 2.0 * Mp * N1 * K0, 16.0 * Mp + 2.0 * Mp * N1 + 4.0 * N1 * K0, counter, Mp)
+        grid = torch.zeros(Bp * Hg * Wg, N2, device=dev, dtype=torch.float32)
+        e0 = ops._prof_begin()
+        lib.call("kd_bf16_pwconv", P(y1), N1, 0, P(u2.conv.weight), P(u2.conv.bias), P(c2.scale), P(c2.shift), u2.act, None, 0, None, 0, 4,
+                 Mp, N1, N2, P(counter), None, None, None, None, 0, P(cell), P(grid), N2, stream())
+        ops._prof_end(e0, "bf16_pw", 2.0 * Mp * N2 * N1, 2.0 * Mp * N1 + 4.0 * Mp + 4.0 * N2 * N1, counter, Mp)
     lidar_map = grid
     if (Hg, Wg) != (cgeom[1], cgeom[2]):        # fusion_module.py:239-240; the BEV grid is fp32, so the fp32 resize serves
         lidar_map = torch.empty(Bp * cgeom[1] * cgeom[2], N2, device=dev, dtype=torch.float32)
@@ -173,7 +200,9 @@ def forward_bf16(model, images: torch.Tensor, points: torch.Tensor, return_inter
         lib.call("kd_bf16_pwconv", P(cat), 2 * C, 0, P(a0.weight), P(a0.bias), P(one), P(zero), ACT_RELU, P(h), C, None, 0, 0, M, 2 * C, C,
                  None, None, None, None, None, 0, None, None, 0, stream())
         fz = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        e0 = ops._prof_begin()
         lib.call("kd_bf16_weighted_tail", P(h), P(cat), P(a2.weight), P(a2.bias), P(fz), M, C, stream())
+        ops._prof_end(e0, "bf16_tail", 6.0 * M * C, 8.0 * M * C)
         fgeom = cgeom
     else:
         raise KDError(f"bf16 path: fusion block {type(fus).__name__} is not supported")
@@ -182,7 +211,9 @@ def forward_bf16(model, images: torch.Tensor, points: torch.Tensor, return_inter
     cls = model.head.cls
     NC, Cin_c = cls.weight.shape[0], cls.weight.shape[1]
     logits = torch.empty(B, NC, hgeom[1], hgeom[2], device=dev, dtype=torch.float32)
+    e0 = ops._prof_begin()
     lib.call("kd_bf16_cls_conv", P(hz), P(cls.weight), P(cls.bias), P(logits), hz.shape[0], hgeom[1] * hgeom[2], Cin_c, NC, stream())
+    ops._prof_end(e0, "bf16_cls", 2.0 * hz.shape[0] * Cin_c * NC, hz.shape[0] * (2.0 * Cin_c + 4.0 * NC))
     if return_intermediates:       # the camera map is widened once (layout plumbing); the BEV grid is fp32 already
         return logits, {"camera_feat": ops.nchw_from_matrix(cam.float(), cgeom), "lidar_feat": ops.nchw_from_matrix(lidar_map, (Bp, cgeom[1], cgeom[2])),
                         "logits": logits}

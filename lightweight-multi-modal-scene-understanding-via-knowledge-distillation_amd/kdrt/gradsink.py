@@ -11,6 +11,8 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
+from . import ops
+
 active: Optional["GradSink"] = None
 
 
@@ -24,6 +26,7 @@ class GradSink:
 
     def begin_step(self):
         self.written.clear()
+        ops.TRANSPOSES.refresh()       # the parameters are final for this step: every W^T the data gradients need, one launch
 
     def buffer(self, p) -> Optional[torch.Tensor]:
         e = self.views.get(id(p))
@@ -38,6 +41,32 @@ class GradSink:
         self.written.add(id(p))
         if self.reducer is not None:
             self.reducer.notify(p)
+
+
+# Feature-map gradient addends.  A loss that reads an intermediate feature map (the KD step's two feature MSEs) deposits its
+# gradient here, keyed by the map's [M, C] matrix; the fusion block that consumed the same map hands it to the data-gradient
+# kernel of its projection as `addend`, so the sum of the two gradient paths is formed inside that kernel instead of by an
+# autograd accumulation pass over the map.  The depositor must check `pending()` is empty after backward (KDStep does): an
+# addend nobody collected would be a silently missing gradient term.
+_addends: Dict[int, torch.Tensor] = {}
+
+
+def deposit(mat: torch.Tensor, grad: torch.Tensor):
+    if mat.shape != grad.shape or not grad.is_contiguous():
+        raise RuntimeError("gradsink.deposit: the addend must be a contiguous tensor shaped like the feature matrix")
+    _addends[mat.data_ptr()] = grad
+
+
+def collect(mat: torch.Tensor) -> Optional[torch.Tensor]:
+    return _addends.pop(mat.data_ptr(), None) if _addends else None
+
+
+def pending() -> int:
+    return len(_addends)
+
+
+def drop_pending():
+    _addends.clear()
 
 
 def install(flat, reducer=None) -> GradSink:

@@ -6,22 +6,28 @@ what BASELINE.json's north_star adds on top of the reference's `return_intermedi
 (fusion_module.py:234,260-262).  Defaults: T=4, alpha=beta=1."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
 
 from . import gradsink, ops, units
 from .ddp import BucketedAllReduce
-from .losses import kd_objective
+from .losses import kd_objective, kd_objective_backward
 from .optim import FusedAdamW
 
 
 class KDStep:
     def __init__(self, student, teacher, optimizer: FusedAdamW, class_weights: Optional[torch.Tensor] = None,
                  T: float = 4.0, alpha: float = 1.0, beta: float = 1.0, ignore_index: int = -1,
-                 reducer: Optional[BucketedAllReduce] = None, teacher_storage: str = "fp32"):
+                 reducer: Optional[BucketedAllReduce] = None, teacher_storage: str = "fp32",
+                 fused_objective: Optional[bool] = None):
         if teacher_storage not in ("fp32", "bf16"):
             raise ValueError(f"teacher_storage must be 'fp32' or 'bf16', got {teacher_storage!r}")
+        # fused objective (default): loss values and loss gradients from the same kernel passes, feature-MSE gradients added
+        # inside the fusion block's data-gradient GEMMs (losses.kd_objective_backward); False / KD_FUSED_OBJECTIVE=0 keeps the
+        # autograd formulation kd_objective(...).backward() -- same bits, more passes (tests compare the two)
+        self.fused_objective = (os.environ.get("KD_FUSED_OBJECTIVE", "1") != "0") if fused_objective is None else bool(fused_objective)
         # "bf16": the frozen teacher runs kdrt.bf16.forward_bf16 (bf16 activations in HBM, fp32 accumulate); a second,
         # separately gated mode -- the default keeps every tensor of the step fp32
         self.teacher_storage = teacher_storage
@@ -40,6 +46,15 @@ class KDStep:
                 return forward_bf16(self.teacher, images, points, return_intermediates=True)
             return self.teacher(images, points, return_intermediates=True)
 
+    def objective_backward(self, zs, ms, zt, mt, labels):
+        """Loss values + the student's backward pass -> (total, parts of detached device scalars)."""
+        a = (zs, ms, zt, mt, labels, self.cw, self.T, self.alpha, self.beta, self.ignore_index)
+        if self.fused_objective:
+            return kd_objective_backward(*a)
+        total, parts = kd_objective(*a)
+        total.backward()
+        return total.detach(), parts
+
     def __call__(self, images, points, labels):
         units.share_point_bins(True)       # teacher and student of THIS step sort the same points once ...
         try:
@@ -50,11 +65,10 @@ class KDStep:
             zs, ms = self.student(images, points, return_intermediates=True)
         finally:
             units.share_point_bins(False)  # ... and nothing of it outlives the two forward passes
-        total, parts = kd_objective(zs, ms, zt, mt, labels, self.cw, self.T, self.alpha, self.beta, self.ignore_index)
-        total.backward()
+        total, parts = self.objective_backward(zs, ms, zt, mt, labels)
         self.opt.grad_scale = self.reducer.finish() if self.reducer is not None else 1.0
         self.opt.step()
-        parts["total"] = total.detach()
+        parts["total"] = total
         parts["logits"] = zs.detach()
         return parts
 
@@ -99,11 +113,10 @@ class GraphedKDStep:
         s.sink.begin_step()
         s.opt.zero_grad()
         zs, ms = s.student(self.images, self.points, return_intermediates=True)
-        total, parts = kd_objective(zs, ms, zt, mt, self.labels, s.cw, s.T, s.alpha, s.beta, s.ignore_index)
-        total.backward()
+        total, parts = s.objective_backward(zs, ms, zt, mt, self.labels)
         s.opt.grad_scale = s.reducer.finish() if s.reducer is not None else 1.0
         s.opt.enqueue_update()
-        parts["total"] = total.detach()
+        parts["total"] = total
         parts["logits"] = zs.detach()
         return parts
 

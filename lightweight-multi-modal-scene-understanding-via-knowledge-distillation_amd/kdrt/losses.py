@@ -5,6 +5,9 @@
   feature_mse   : F.mse_loss forward + gradient
   kd_objective  : CE + alpha*T^2*KL + beta*(MSE(cam) + MSE(lidar))   (the
                   reference has no KD code -- this definition is the build's specification)
+  kd_objective_backward : the same objective AND its backward pass for the training step: every loss kernel
+                  produces its value and its gradient in one pass (the root's upstream gradient is 1), the
+                  feature-MSE gradients ride into the fusion block's data-gradient GEMMs as addends
   confusion     : argmax + confusion matrix of SegmentationMetrics.update (trainer.py:18-26)
 """
 from __future__ import annotations
@@ -13,9 +16,19 @@ from typing import Dict, Optional
 
 import torch
 
-from . import ops
+import numpy as np
+
+from . import gradsink, ops
 from .lib import KDError, lib
 from .ops import P, stream
+
+
+def _check_target(logits, target):
+    """The loss kernels index the target as [B, H, W] of the logits: anything else would read past its end."""
+    B, _, H, W = logits.shape
+    if tuple(target.shape) != (B, H, W) or target.device != logits.device:
+        raise KDError(f"segmentation target {tuple(target.shape)} on {target.device} does not match the logits' "
+                      f"[B, H, W] = {(B, H, W)} on {logits.device}")
 
 
 class _SegLossFn(torch.autograd.Function):
@@ -38,6 +51,7 @@ class _SegLossFn(torch.autograd.Function):
         target = target.contiguous()
         if target.dtype != torch.int64:
             raise KDError("segmentation target must be int64")
+        _check_target(zs_c, target)
         losses = torch.empty(4, device=zs.device, dtype=torch.float32)
         _SegLossFn._call(zs_c, zt_c, target, class_w, ignore_index, T, alpha, None, losses, None)
         ctx.args = (zs_c, zt_c, target, class_w, ignore_index, T, alpha)
@@ -106,11 +120,62 @@ def kd_objective(student_logits, student_mids: Dict[str, torch.Tensor], teacher_
     return total, {"ce": ce.detach(), "kl": kl.detach(), "mse_cam": mse_c.detach(), "mse_lidar": mse_l.detach()}
 
 
+def kd_objective_backward(student_logits, student_mids: Dict[str, torch.Tensor], teacher_logits, teacher_mids, target,
+                          class_weights=None, T: float = 4.0, alpha: float = 1.0, beta: float = 1.0, ignore_index: int = -1):
+    """kd_objective(...)[0].backward() in one: returns (total, parts) with the student's gradients already propagated.
+
+    Same values and the same gradient bits as the autograd formulation, fewer passes: the segmentation-loss call writes
+    dL/dlogits together with CE / KL; each feature MSE writes its gradient in the pass that sums its value, and that
+    gradient is deposited (gradsink.deposit) for the fusion block's projection of the same map, whose data-gradient GEMM
+    adds it in its epilogue -- no gradient-accumulation pass over the [B, 128, H, W] maps, no scalar-arithmetic kernels."""
+    zs = student_logits
+    ops.require_gpu_tensor(zs, "kd_objective_backward")
+    if not zs.requires_grad:
+        raise KDError("kd_objective_backward: the student logits carry no autograd graph (was the forward run under no_grad?)")
+    dev = zs.device
+    zs_c = zs.detach().contiguous()
+    zt_c = teacher_logits.detach().contiguous()
+    target = target.contiguous()
+    if target.dtype != torch.int64:
+        raise KDError("segmentation target must be int64")
+    _check_target(zs_c, target)
+    B, NC, H, W = zs_c.shape
+    vals = torch.empty(8, device=dev, dtype=torch.float32)        # [0:4] seg-loss values, [4] mse_cam, [5] mse_lidar, [6] total
+    dzs = torch.empty_like(zs_c)
+    nbytes = lib.kd_seg_loss_ws_bytes(B * H * W)
+    ws = ops.workspace(nbytes, dev)
+    lib.call("kd_seg_loss_fwd_bwd", P(zs_c), P(zt_c), P(target), P(class_weights), int(ignore_index), float(T), float(alpha),
+             1.0, None, P(vals), P(dzs), B, NC, H * W, P(ws), nbytes, stream())
+    roots, grads = [zs], [dzs]
+    gradsink.drop_pending()
+    for slot, key in ((4, "camera_feat"), (5, "lidar_feat")):
+        a, b = student_mids[key], teacher_mids[key]
+        am, _ = ops.nhwc_view(a.detach())
+        bm, _ = ops.nhwc_view(b.detach())
+        n = am.numel()
+        want = beta != 0.0 and a.requires_grad
+        da = torch.empty_like(am) if want else None
+        nbytes = lib.kd_mse_ws_bytes(n)
+        ws = ops.workspace(nbytes, dev)
+        gcoef = float(np.float32(2.0 / n) * np.float32(beta))      # the product autograd's fp32 chain rule forms
+        lib.call("kd_mse_fwd_bwd", P(am), P(bm), n, gcoef, None, P(vals[slot:]), P(da), P(ws), nbytes, stream())
+        if want:
+            gradsink.deposit(am, da)
+    lib.call("kd_kd_total", P(vals), P(vals[4:]), P(vals[5:]), float(alpha * T * T), float(beta), P(vals[6:]), stream())
+    torch.autograd.backward(roots, grads)
+    if gradsink.pending():
+        gradsink.drop_pending()
+        raise KDError("kd_objective_backward: a feature-map gradient was not collected by the fusion block's backward "
+                      "(unsupported model structure for the fused objective; use kd_objective(...).backward())")
+    return vals[6], {"ce": vals[0], "kl": vals[1], "mse_cam": vals[4], "mse_lidar": vals[5]}
+
+
 def confusion(logits, target, num_classes: int = 2, ignore_index: int = -1, out: Optional[torch.Tensor] = None):
     """Accumulates into (or creates) an int64 [C, C] device confusion matrix; returns (conf, argmax)."""
     ops.require_gpu_tensor(logits, "confusion")
     z = logits.detach().contiguous()
     B, NC, H, W = z.shape
+    _check_target(z, target)
     if out is None:
         out = torch.zeros(num_classes, num_classes, device=z.device, dtype=torch.int64)
     pred = torch.empty(B, H, W, device=z.device, dtype=torch.int64)

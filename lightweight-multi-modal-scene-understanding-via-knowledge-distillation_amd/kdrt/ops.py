@@ -332,7 +332,70 @@ def pw_wgrad(D, A, dW, *, M, N, K, X=None, d_mode=0, d_act=0, al=None, be=None, 
     _prof_end(e0, "pw_wgrad", 2.0 * M * N * K, 4.0 * (M * N * (2 if d_mode == 2 else 1) + M * K + N * K), None, M)
 
 
-def transpose(w2d: torch.Tensor) -> torch.Tensor:
+class TransposeCache:
+    """W^T of every weight the data-gradient GEMMs need, refreshed by ONE launch per step instead of one per weight.
+
+    `transpose(w)` registers a weight the first time it sees it (and transposes it on its own that time).  `refresh()` -- called
+    by the gradient sink at the start of a step, when the parameters are final for that step -- re-transposes all registered
+    weights with kd_transpose_batch and stamps them with the current parameter epochs; `transpose(w)` then hands out the
+    cached W^T as long as the stamp still matches (any optimiser update, graph replay or broadcast moves an epoch, after
+    which the per-weight launch is used again until the next refresh).  The W^T buffers are persistent, so a captured
+    hipGraph that contains the refresh launch and their readers replays correctly."""
+
+    def __init__(self):
+        self.entries = {}          # (data_ptr, R, C) -> [weight view, W^T buffer, stamp, owning parameter]
+        self.table = None
+        self.nblocks = 0
+        self.enabled = _os.environ.get("KD_TRANSPOSE_CACHE", "1") != "0"
+
+    @staticmethod
+    def _stamp(e):
+        return (GLOBAL_EPOCH[0], owner_epoch(e[3]), e[3]._version)
+
+    def get(self, w2d, owner):
+        if not self.enabled or owner is None:
+            return None
+        key = (w2d.data_ptr(), w2d.shape[0], w2d.shape[1])
+        e = self.entries.get(key)
+        if e is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            R, Cc = w2d.shape
+            self.entries[key] = [w2d.detach(), torch.empty(Cc, R, device=w2d.device, dtype=torch.float32), None, owner]
+            self.table = None
+            return None
+        return e[1] if e[2] == self._stamp(e) else None
+
+    def refresh(self):
+        if not self.enabled or not self.entries:
+            return
+        ents = list(self.entries.values())
+        if self.table is None:
+            rows, blk = [], 0
+            for w, wt, _, _ in ents:
+                rows.append([w.data_ptr(), wt.data_ptr(), w.shape[0], w.shape[1], blk])
+                blk += (w.numel() + 255) // 256
+            if torch.cuda.is_current_stream_capturing():
+                return                                     # (a new weight showed up after warm-up: leave it to the per-weight launch)
+            self.table = torch.tensor(rows, dtype=torch.int64).to(ents[0][0].device)
+            self.nblocks = blk
+        lib.call("kd_transpose_batch", P(self.table), len(ents), self.nblocks, stream())
+        for e in ents:
+            e[2] = self._stamp(e)
+
+    def clear(self):
+        self.entries.clear()
+        self.table = None
+
+
+TRANSPOSES = TransposeCache()
+
+
+def transpose(w2d: torch.Tensor, owner: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """W^T as a fresh tensor, or -- when `owner` names the parameter `w2d` is a view of -- from the per-step cache."""
+    cached = TRANSPOSES.get(w2d, owner)
+    if cached is not None:
+        return cached
     R, Cc = w2d.shape
     out = torch.empty(Cc, R, device=w2d.device, dtype=torch.float32)
     lib.call("kd_transpose", P(w2d), P(out), R, Cc, stream())

@@ -312,7 +312,7 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
             ops.pw_wgrad(t, inp.raw, dW, M=M, N=N, K=K, X=y, d_mode=2, d_act=mact, al=al, be=be, ga=ga, msc=msc, msh=msh,
                          a_mode=1 if inp.bnc is not None else 0, a_act=inp.act, asc=inp.sc, ash=inp.sh)
         if need_input_grad:
-            Wt = ops.transpose(rec.w.view(N, K))
+            Wt = ops.transpose(rec.w.view(N, K), owner=rec.w)
             if fused1:
                 rows_in = lib.kd_lidar_l1_bwd_stat_rows(M)
                 part_in = torch.empty(rows_in * 2 * K, device=dev, dtype=torch.float32)
@@ -618,13 +618,21 @@ def _proj_pair(cam, lid, u_cam: UnitSpec, u_lid: UnitSpec, training):
     return cat, comb, (op_c, rec_c), (op_l, rec_l), geom
 
 
+def _feature_addend(rec, need_input_grad):
+    """A gradient another consumer of this projection's input map left for it (gradsink.deposit): summed into the data
+    gradient by the GEMM itself.  Only a materialised input can have one."""
+    if not need_input_grad or rec.inp.bnc is not None or rec.inp.raw is None:
+        return None
+    return gradsink.collect(rec.inp.raw)
+
+
 def _proj_pair_backward(ctx, gcat, partial, rows, Cc, Cl, need_cam, need_lid):
     """Split the masked gradient of the concat buffer between the two projection units."""
     tot = Cc + Cl
     g_c = ("G", gcat[:, :Cc], partial, rows, tot)
     g_l = ("G", gcat[:, Cc:], partial[Cc:], rows, tot)
-    pg_c, dcam = unit_backward(ctx.rec_c, g_c, need_input_grad=need_cam)
-    pg_l, dlid = unit_backward(ctx.rec_l, g_l, need_input_grad=need_lid)
+    pg_c, dcam = unit_backward(ctx.rec_c, g_c, need_input_grad=need_cam, addend=_feature_addend(ctx.rec_c, need_cam))
+    pg_l, dlid = unit_backward(ctx.rec_l, g_l, need_input_grad=need_lid, addend=_feature_addend(ctx.rec_l, need_lid))
     dcam = ops.nchw_from_matrix(dcam, ctx.rec_c.inp.geom) if need_cam else None
     dlid = ops.nchw_from_matrix(dlid, ctx.rec_l.inp.geom) if need_lid else None
     return dcam, dlid, pg_c, pg_l
@@ -714,7 +722,7 @@ class WeightedFuseFn(torch.autograd.Function):
         db2 = gradsink.deliver(ctx.b2, dpar[3 * C: 3 * C + 2])
         dw1, w1_dir = gradsink.out_for(ctx.w1)
         ops.pw_wgrad(gh, cat, dw1, M=M, N=C, K=2 * C, d_mode=0, a_mode=1, a_act=ACT_RELU, asc=comb.scale, ash=comb.shift)
-        w1t = ops.transpose(ctx.w1.view(C, 2 * C))
+        w1t = ops.transpose(ctx.w1.view(C, 2 * C), owner=ctx.w1)
         rows = lib.kd_pwconv_stat_rows_for(M, C, 2 * C, 0, 2, 1)           # (reduction width C, output width 2C)
         partial = torch.empty(rows * 2 * 2 * C, device=dev, dtype=torch.float32)
         gcat = torch.empty(M, 2 * C, device=dev, dtype=torch.float32)
@@ -749,8 +757,10 @@ class MinimalFuseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         dm, _ = ops.nhwc_view(dout)
-        pg_c, dcam = unit_backward(ctx.rec_c, ("D", dm), need_input_grad=ctx.needs_input_grad[0])
-        pg_l, dlid = unit_backward(ctx.rec_l, ("D", dm), need_input_grad=ctx.needs_input_grad[1])
+        pg_c, dcam = unit_backward(ctx.rec_c, ("D", dm), need_input_grad=ctx.needs_input_grad[0],
+                                   addend=_feature_addend(ctx.rec_c, ctx.needs_input_grad[0]))
+        pg_l, dlid = unit_backward(ctx.rec_l, ("D", dm), need_input_grad=ctx.needs_input_grad[1],
+                                   addend=_feature_addend(ctx.rec_l, ctx.needs_input_grad[1]))
         dcam = ops.nchw_from_matrix(dcam, ctx.rec_c.inp.geom) if dcam is not None else None
         dlid = ops.nchw_from_matrix(dlid, ctx.rec_l.inp.geom) if dlid is not None else None
         return (dcam, dlid, None, None, None, *pg_c, *pg_l)

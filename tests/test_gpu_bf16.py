@@ -13,6 +13,12 @@ pytestmark = pytest.mark.gpu
 # logit range, argmax agreement 99.41-99.88 %; bf16 keeps 8 mantissa bits per stored activation through ~25 layers
 LOGIT_TOL_REL = 1.5e-2
 ARGMAX_MIN = 0.99
+# Weighted fusion has its own logit bound.  Its two attention logits go through a softmax, and with the seeded random weights
+# the logit DIFFERENCE has a standard deviation of ~30 (a trained block is far milder), so wherever the two are close the
+# weights w = softmax(a) move by up to |da| / 4 per unit of logit error: the bf16 rounding of the projected maps alone
+# (|da| <= 0.35; fp32 `h` and fp32 attention weights do not lower it -- emulated on the CPU oracle) moves single pixels by
+# 2-4 % of the logit range.  Measured: 1.32 / 3.50 / 1.34 % at the three shapes, argmax agreement 99.41-100 % (same bound).
+LOGIT_TOL_REL_WEIGHTED = 5e-2
 
 
 # the third shape has an 8 x 8 BEV grid under a 16 x 16 camera map: the bilinear LiDAR resize of fusion_module.py:239-240
@@ -33,14 +39,15 @@ def test_bf16_forward_against_fp32_and_oracle(fusion, shape):
     err = (z16 - z32).abs().max().item()
     agree = (z16.argmax(1) == z32.argmax(1)).float().mean().item()
     print(f"bf16 vs fp32 HIP [{fusion} {shape}]: max|dlogit| {err:.4f} = {err / rng:.2%} of range {rng:.2f}, argmax agreement {agree:.4%}")
-    assert err <= LOGIT_TOL_REL * rng, (err, rng)
+    tol = LOGIT_TOL_REL_WEIGHTED if fusion == "weighted" else LOGIT_TOL_REL
+    assert err <= tol * rng, (err, rng)
     assert agree >= ARGMAX_MIN, agree
     if True:                                         # the CPU oracle too, at both shapes (eval forward of 2 frames: < 1 s)
         with torch.no_grad():
             zo, _ = O.complete_model(images, pts, O.clone_state(st), fusion_type=fusion, grid=(G, G), training=False)
         err_o = (z16.cpu() - zo).abs().max().item()
         agree_o = (z16.cpu().argmax(1) == zo.argmax(1)).float().mean().item()
-        assert err_o <= LOGIT_TOL_REL * rng and agree_o >= ARGMAX_MIN, (err_o, agree_o)
+        assert err_o <= tol * rng and agree_o >= ARGMAX_MIN, (err_o, agree_o)
 
 
 def test_bf16_mode_is_gated():
@@ -98,3 +105,25 @@ def test_kd_step_with_bf16_teacher(teacher_fusion):
     assert cos >= KD_GRAD_COS_MIN and abs(nrm - 1) < 5e-2
     with pytest.raises(ValueError):
         KDStep(student, teacher, opt, cw, teacher_storage="fp16")
+
+
+def test_bf16_one_kernel_lidar_encoder_against_the_two_launches(monkeypatch):
+    """kd_bf16_lidar_mlp_scatter (point MLP + scatter-max in one kernel, nothing between the layers in HBM) against the two
+    kd_bf16_pwconv launches it replaces: the same roundings (operands to bf16 once, fp32 accumulation); only the order of the
+    sums inside a dot product differs, which can move a layer-1 activation by one bf16 step (2^-8 relative) before layer 2."""
+    from kdrt import bf16
+    B, HW, N, G = 2, 256, 5000, 64
+    images, pts, _ = O.make_inputs(B, HW, N, G, 5, pad_tail=60)
+    model = build_product("concat", G)
+    load_random_state(model, "concat", 21)
+    model.eval()
+    _, one = bf16.forward_bf16(model, images.cuda(), pts.cuda(), return_intermediates=True)
+    monkeypatch.setattr(bf16, "_LIDAR_ONE_KERNEL", False)
+    _, two = bf16.forward_bf16(model, images.cuda(), pts.cuda(), return_intermediates=True)
+    a, b = one["lidar_feat"], two["lidar_feat"]
+    assert a.shape == b.shape and (a > 0).any()
+    assert torch.equal(a == 0, b == 0)                                   # the same cells / channels are occupied
+    err = (a - b).abs().max().item() / b.abs().max().item()
+    print(f"one-kernel bf16 LiDAR encoder vs two launches: max |diff| = {err:.2e} of the map's maximum")
+    assert err <= 4e-3
+    assert (one["logits"] - two["logits"]).abs().max().item() <= 1e-2 * (two["logits"].max() - two["logits"].min()).item()
