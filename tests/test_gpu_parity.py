@@ -193,15 +193,13 @@ def test_kd_step_vs_oracle_and_adamw():
         assert d[~tiny].max().item() < 2e-6 * max(1.0, want.abs().max().item()) if (~tiny).any() else True, k
 
 
-def _fp64_cases():
-    """(objective, student fusion, input seed) triples whose batch keeps every pre-activation clear of a ReLU / ReLU6 /
-    max kink in EVERY evaluation (CPU fp32 oracle, GPU in both GEMM arithmetics, streaming on / off): found by
-    tools/diag_fp64_seeds.py on an MI355X, scan output in profiles/r03_fp64_seed_scan.txt, list in
-    tests/golden/fp64_clean_seeds.json.  On such seeds no tolerance games are needed."""
+def _fp64_table():
+    """{"kd/weighted": [seeds], ...}: input seeds whose batch kept every pre-activation clear of a ReLU / ReLU6 / max kink in
+    EVERY evaluation (CPU fp32 oracle, GPU in both GEMM arithmetics, streaming mode 0 / 1 / 2) when tools/diag_fp64_seeds.py
+    scanned them on an MI355X (scan output in profiles/r03_fp64_seed_scan.txt, list in tests/golden/fp64_clean_seeds.json)."""
     import json
     import os
-    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp64_clean_seeds.json")))
-    return [(k.split("/")[0], k.split("/")[1], sd) for k, seeds in sorted(tab["clean"].items()) for sd in seeds]
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp64_clean_seeds.json")))["clean"]
 
 
 def _fp64_check(objective, fusion, seed):
@@ -212,27 +210,38 @@ def _fp64_check(objective, fusion, seed):
     return cpu, gpu
 
 
-@pytest.mark.parametrize("objective,fusion,seed", _fp64_cases())
-def test_gradients_against_fp64_oracle(objective, fusion, seed):
+@pytest.mark.parametrize("case", sorted(_fp64_table()))
+def test_gradients_against_fp64_oracle(case):
     """Gradient accuracy without the flip-tolerant comparison: the oracle evaluated in float64 is the ground truth, and the
     GPU gradients of the whole step (KD: concat teacher -> concat / minimal / weighted student; CE: the reference's plain
     step) must be as close to it as the fp32 CPU oracle is (measured: both ~2.5e-6 median, < 1e-5 max) -- a systematic
-    error of a few 1e-4 (round 2's statistics-slab row-count bug) is 100x over the line."""
-    cpu, gpu = _fp64_check(objective, fusion, seed)
-    assert len(gpu) > 75
+    error of a few 1e-4 (round 2's statistics-slab row-count bug) is 100x over the line.
+
+    Three scanned seeds per case, at least TWO must pass.  Whether a batch sits on a kink depends on the last bit of every
+    sum before it, so any later change of a summation order (a new reduction layout, another tile shape) can move ONE of the
+    committed batches onto a kink -- a 1e-2-class error in that batch alone, which says nothing about the kernels; a real
+    gradient error fails all three.  A failing seed is reported so the table can be re-scanned."""
+    objective, fusion = case.split("/")
+    seeds = _fp64_table()[case]
+    assert len(seeds) >= 3, "tests/golden/fp64_clean_seeds.json: three scanned seeds per case"
     med = lambda v: v[len(v) // 2]
-    assert med(gpu) <= max(3 * med(cpu), 1e-5) and gpu[-1] <= max(3 * cpu[-1], 5e-5), (med(gpu), gpu[-1], med(cpu), cpu[-1])
+    verdicts = []
+    for seed in seeds[:3]:
+        cpu, gpu = _fp64_check(objective, fusion, seed)
+        assert len(gpu) > 75
+        verdicts.append((seed, med(gpu) <= max(3 * med(cpu), 1e-5) and gpu[-1] <= max(3 * cpu[-1], 5e-5), med(gpu), gpu[-1], med(cpu), cpu[-1]))
+    bad = [v for v in verdicts if not v[1]]
+    for v in bad:
+        print(f"{case} seed {v[0]}: GPU median {v[2]:.2e} max {v[3]:.2e} vs CPU fp32 {v[4]:.2e} / {v[5]:.2e} -- re-scan (tools/diag_fp64_seeds.py)")
+    assert len(bad) <= 1, verdicts
 
 
 def test_fp64_gradient_check_goes_red_on_a_wrong_statistics_row_count(monkeypatch):
     """Teeth: re-create round 2's bug class -- BatchNorm-backward reductions that sum one slab row too few -- behind the
     library's back (the C ABI's own row-count guard cannot see a short REDUCTION) and require the float64 check to fail by
     a wide margin.  The flip-tolerant model-level comparison (grads_match, 1e-2) let a 3e-4 error through in round 2."""
-    import json
-    import os
     from kdrt import ops
-    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp64_clean_seeds.json")))
-    seed = tab["clean"]["kd/weighted"][0]
+    seed = _fp64_table()["kd/weighted"][0]
     real = ops.bn_bwd_finalize
     calls = []
 
