@@ -506,7 +506,7 @@ def main():
                 "replaces": "kd_lidar_l2_dgrad + _l2_wgrad + _l1_dgrad + _l1_wgrad: 21.8 ms and 94 GB of operand passes per step in round 2"}
         # HBM bytes per launch come from PMC counters, which need their own rocprofv3 passes: use the committed
         # measurement of this exact workload (profiles/), null for any other configuration
-        for fn in ("r02_bench_pmc_traffic_B256.json", "r01_bench_pmc_traffic_B256.json"):
+        for fn in ("r03_bench_pmc_traffic_B256.json", "r02_bench_pmc_traffic_B256.json", "r01_bench_pmc_traffic_B256.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 wl = pmc["workload"]
@@ -524,7 +524,7 @@ def main():
                     break
             except (OSError, KeyError, ValueError):
                 continue
-    if rank == 0 and world == 1 and not args.no_bf16_forward and args.teacher_fusion in ("concat", "minimal"):
+    if rank == 0 and world == 1 and not args.no_bf16_forward:
         # The same KD step with the frozen teacher on the bf16-storage path (KDStep(teacher_storage="bf16")): a second
         # mode reported BESIDE the fp32 headline, never instead of it.  Student forward / backward / AdamW stay fp32.
         if reducer is not None:

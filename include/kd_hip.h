@@ -104,6 +104,15 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
                      const float* sh, int act, const float* mean, const float* invstd, const float* w, float* gx,
                      float* partial, float* dw, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes,
                      void* stream);
+/* the same with a second gradient path into the conv's input (the residual of an inverted-residual block whose first
+ * convolution is this one, camera_encoder.py:46-51 at expansion_ratio 1): gx = (conv^T dy + addend) * act'(.), sums included.
+ * Needs both gradients and a shape kd_dwconv3x3_bwd_add_supported() accepts (the stride-1 column-walk form). */
+int kd_dwconv3x3_bwd_add_supported(int C, int W, int stride);
+int kd_dwconv3x3_bwd_add(const float* D, const float* Y, const float* al, const float* be, const float* ga,
+                         const float* dsc, const float* dsh, int d_act, const float* x, const float* sc,
+                         const float* sh, int act, const float* mean, const float* invstd, const float* w,
+                         const float* addend, float* gx, float* partial, float* dw, int B, int H, int W, int C, int stride,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* ---- BatchNorm coefficient kernels (nn.BatchNorm1d/2d: eps 1e-5, momentum 0.1) ---------------- */
 int kd_bn_finalize_train(float* partial, int rows, int C, int pstride, int64_t count, const float* gamma,
@@ -115,6 +124,9 @@ int kd_bn_eval_coeffs(const float* gamma, const float* beta, const float* runnin
 int64_t kd_rowwise_stat_rows(int64_t M, int C);
 int kd_bn_act_apply(const float* x, int64_t ldx, const float* sc, const float* sh, int act, const float* res,
                     int64_t ldr, float* out, int64_t ldo, int64_t M, int C, void* stream);
+/* the same with a residual that is itself deferred: out = act(x*sc+sh) + ract(res*rsc+rsh) */
+int kd_bn_act_apply_res(const float* x, int64_t ldx, const float* sc, const float* sh, int act, const float* res, int64_t ldr,
+                        const float* rsc, const float* rsh, int ract, float* out, int64_t ldo, int64_t M, int C, void* stream);
 int kd_bn_bwd_reduce(const float* D, int64_t ldd, const float* X, int64_t ldx, const float* sc, const float* sh,
                      int act, const float* mean, const float* invstd, float* partial, int64_t M, int C,
                      void* stream);

@@ -163,19 +163,22 @@ struct ApplyArgs {
   const float* x; int64_t ldx; const float* sc; const float* sh; int act;
   const float* res; int64_t ldr; float* out; int64_t ldo;
   int64_t M; int C; int groups, slots; int nt;
+  const float* rsc; const float* rsh; int ract;       // the residual is itself a deferred tensor: res = ract(res_raw * rsc + rsh)
 };
 __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
   const int tid = threadIdx.x;
   const int gidx = tid % a.groups, slot = tid / a.groups;
   if (slot >= a.slots) return;
   const int c0 = gidx * 4;
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4();
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4(), rsc = sc, rsh = sh;
   if (a.sc) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
+  if (a.rsc) { rsc = kd_ld4(a.rsc + c0); rsh = kd_ld4(a.rsh + c0); }
   for (int64_t m = (int64_t)blockIdx.x * a.slots + slot; m < a.M; m += (int64_t)gridDim.x * a.slots) {
     float4 v = kd_ld4(a.x + m * a.ldx + c0);
     v = kd_affine_act4(v, sc, sh, a.act);
     if (a.res) {
-      const float4 r = kd_ld4(a.res + m * a.ldr + c0);
+      float4 r = kd_ld4(a.res + m * a.ldr + c0);
+      if (a.rsc) r = kd_affine_act4(r, rsc, rsh, a.ract);
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
     if (a.nt) kd_st4_nt(a.out + m * a.ldo + c0, v); else kd_st4(a.out + m * a.ldo + c0, v);
@@ -255,9 +258,21 @@ int kd_bn_act_apply(const float* x, int64_t ldx, const float* sc, const float* s
   KD_REQUIRE(x && out && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, KD_ERR_ARG, "kd_bn_act_apply: bad args (C=%d)", C);
   KD_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && (!res || ldr % 4 == 0), KD_ERR_SHAPE, "kd_bn_act_apply: ld must be a multiple of 4");
   const KdCgLayout l = kd_cg_layout(M, C);
-  ApplyArgs a{x, ldx, sc, sh, act, res, ldr, out, ldo, M, C, l.groups, l.slots, kd_nt_store((size_t)M * C * sizeof(float))};
+  ApplyArgs a{x, ldx, sc, sh, act, res, ldr, out, ldo, M, C, l.groups, l.slots, kd_nt_store((size_t)M * C * sizeof(float)), nullptr, nullptr, 0};
   hipLaunchKernelGGL(bn_apply_kernel, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   return kd_check_launch("kd_bn_act_apply");
+}
+
+// out = act(x*sc+sh) + ract(res*rsc+rsh): the residual is a deferred tensor too (raw conv output + its BatchNorm coefficients),
+// e.g. the stem's output under stage 1's residual connection -- it never has to exist in HBM in activated form.
+int kd_bn_act_apply_res(const float* x, int64_t ldx, const float* sc, const float* sh, int act, const float* res, int64_t ldr,
+                        const float* rsc, const float* rsh, int ract, float* out, int64_t ldo, int64_t M, int C, void* stream) {
+  KD_REQUIRE(x && out && res && rsc && rsh && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, KD_ERR_ARG, "kd_bn_act_apply_res: bad args (C=%d)", C);
+  KD_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0, KD_ERR_SHAPE, "kd_bn_act_apply_res: ld must be a multiple of 4");
+  const KdCgLayout l = kd_cg_layout(M, C);
+  ApplyArgs a{x, ldx, sc, sh, act, res, ldr, out, ldo, M, C, l.groups, l.slots, kd_nt_store((size_t)M * C * sizeof(float)), rsc, rsh, ract};
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  return kd_check_launch("kd_bn_act_apply_res");
 }
 
 // partial[grid][2][C] = (sum G, sum G*xhat) with G = D * act'(X*sc+sh), xhat = (X-mean)*invstd.

@@ -114,6 +114,8 @@ struct DwBwdArgs {
   const float* w;
   float* gx; float* partial;           // data: G_x [B,H,W,C] (masked) + stats slab [grid][2][C]
   float* wslab;                        // weight: slab [grid][C*9]
+  const float* addend;                 // optional [B,H,W,C]: a second gradient path into the same input (the block's residual),
+                                       // added to the data gradient BEFORE the activation mask (fused stride-1 column walk only)
   int B, H, W, C, Ho, Wo, stride;
   int groups, slots, nchunk;     // channel quads per chunk, adjacent columns per block, channel chunks (dw_layout)
   int nt;                              // large gx: non-temporal stores
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_sw_kernel(DwBwdArgs a) {
 // its dy window (see the loop).  The raw centre of each input row doubles as the operand of the activation mask and of
 // the BatchNorm-backward sums.  A segment's last dy row and first / last input rows reach into the neighbouring segments:
 // every (dy row, input row) pair is still counted exactly once, by the segment that owns the INPUT row.
+template <bool ADD>
 __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
   __shared__ float red[2 * 256 * 4];
   __shared__ __attribute__((aligned(16))) float wl[9 * 1024];   // flipped taps, [tap][channel]: wl[t][c] = w[c][8 - t] (C <= 1024)
@@ -399,7 +402,10 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
       // hi + 1 and the raw input row hi are requested before the store of row hi - 1 is issued.
       DwRaw nl = dw_dy_raw_s1(a, b, h0 + 1, wi - 1, c0), nc = dw_dy_raw_s1(a, b, h0 + 1, wi, c0), nr = dw_dy_raw_s1(a, b, h0 + 1, wi + 1, c0);
       DwRow xn = dw_load_row_raw(a.x, b, h0, wi, a.H, a.W, a.C, c0);
+      float4 adn = kd_zero4();
+      if (ADD) adn = kd_ld4(a.addend + (((int64_t)b * a.H + h0) * a.W + wi) * a.C + c0);
       for (int hi = h0; hi < h1; ++hi) {
+        const float4 ad = adn;
         {
           const bool hok = hi + 1 < a.Ho;
           r2.l = dw_dy_finish(a, nl, hok && wi - 1 >= 0, al, be, ga, dsc, dsh);
@@ -410,6 +416,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
         const DwRow xa = dw_finish_row(xn, deferred, sc, sh, a.act, hi, wi, a.H, a.W);
         nl = dw_dy_raw_s1(a, b, hi + 2, wi - 1, c0); nc = dw_dy_raw_s1(a, b, hi + 2, wi, c0); nr = dw_dy_raw_s1(a, b, hi + 2, wi + 1, c0);
         xn = dw_load_row_raw(a.x, b, hi + 1 < a.H ? hi + 1 : hi, wi, a.H, a.W, a.C, c0);
+        if (ADD) adn = kd_ld4(a.addend + (((int64_t)b * a.H + (hi + 1 < a.H ? hi + 1 : hi)) * a.W + wi) * a.C + c0);
         // ---- weight gradient.  dw[kh][kw] = sum_ho dy(ho) x(ho - 1 + kh, wo - 1 + kw): the input row hi pairs with the dy
         // centres of rows hi + 1 (kh = 0), hi (kh = 1), hi - 1 (kh = 2), all three in the dy window (zero outside the image),
         // so no input window is kept: every input row is activated once and used once. ---------------------------------
@@ -428,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
         fma_row(acc, r1, 1);
         fma_row(acc, r2, 2);
         const int64_t p = ((int64_t)b * a.H + hi) * a.W + wi;
+        if (ADD) { acc.x += ad.x; acc.y += ad.y; acc.z += ad.z; acc.w += ad.w; }
         if (deferred) {
           acc.x *= kd_act_mask(kd_affine(xr.x, sc.x, sh.x), a.act);
           acc.y *= kd_act_mask(kd_affine(xr.y, sc.y, sh.y), a.act);
@@ -1001,30 +1009,43 @@ size_t kd_dwconv_bwd_ws_bytes(int64_t npix_out, int C) {
 // Backward of y = dwconv3x3(act(x*sc+sh)).  (D, Y, al, be, ga[, dsc, dsh, d_act]) describe dL/dy_raw;
 // outputs: gx (masked gradient w.r.t. the activated input, with BN-backward sums in `partial`)
 // and dw [C][9].  gx == null skips the data gradient, dw == null the weight gradient.
-int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const float* be, const float* ga,
-                     const float* dsc, const float* dsh, int d_act, const float* x, const float* sc, const float* sh,
-                     int act, const float* mean, const float* invstd, const float* w, float* gx, float* partial,
-                     float* dw, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream) {
-  KD_REQUIRE(D && x && w && B > 0 && C % 4 == 0 && C <= 1024, KD_ERR_ARG, "kd_dwconv3x3_bwd: bad args");
-  KD_REQUIRE(!al || (Y && be && ga), KD_ERR_ARG, "kd_dwconv3x3_bwd: al needs Y, be, ga");
-  KD_REQUIRE(!sc || (sh && (!partial || (mean && invstd))), KD_ERR_ARG, "kd_dwconv3x3_bwd: sc needs sh (+mean/invstd for stats)");
-  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-  hipStream_t st = (hipStream_t)stream;
+static int dw_fused_form(int C, int W, int stride) {       // 1 column walk, 2 tile form (stride 1); the default choice by shape
   int dw_mode = kd_dw_fused_mode();
   // by shape (tools/bench_dw at 256 frames, round 3, with the channel-chunked column walk): the tile form wins on every
   // stride-1 shape of the step from 64 channels up (64: 283 vs 323 us, 128: 523 vs 573, 256: 968 vs 1054, 384: 1319 vs 1500, 768 at 32 x 32:
   // 695 vs 784); below a 64-channel chunk it idles lanes (32 channels: 810 vs 575)
-  if (dw_mode == 3) dw_mode = (C >= 64 && C % 64 == 0 && W >= 16) ? 2 : 1;
+  if (dw_mode == 3) dw_mode = (stride == 1 && C >= 64 && C % 64 == 0 && W >= 16) ? 2 : 1;
+  return dw_mode;
+}
+
+// 1 when kd_dwconv3x3_bwd_add can fold a residual gradient into this shape's one-pass backward (the stride-1 column walk)
+int kd_dwconv3x3_bwd_add_supported(int C, int W, int stride) { return stride == 1 && C % 4 == 0 && C <= 1024 && dw_fused_form(C, W, stride) == 1; }
+
+static int dw_bwd_impl(const float* D, const float* Y, const float* al, const float* be, const float* ga,
+                       const float* dsc, const float* dsh, int d_act, const float* x, const float* sc, const float* sh,
+                       int act, const float* mean, const float* invstd, const float* w, float* gx, float* partial,
+                       float* dw, const float* addend, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream) {
+  KD_REQUIRE(D && x && w && B > 0 && C % 4 == 0 && C <= 1024, KD_ERR_ARG, "kd_dwconv3x3_bwd: bad args");
+  KD_REQUIRE(!addend || (gx && dw && kd_dwconv3x3_bwd_add_supported(C, W, stride) && kd_aligned16(addend)), KD_ERR_SHAPE,
+             "kd_dwconv3x3_bwd_add: a residual addend needs both gradients and the stride-1 column-walk form (C=%d W=%d stride=%d)", C, W, stride);
+  KD_REQUIRE(!al || (Y && be && ga), KD_ERR_ARG, "kd_dwconv3x3_bwd: al needs Y, be, ga");
+  KD_REQUIRE(!sc || (sh && (!partial || (mean && invstd))), KD_ERR_ARG, "kd_dwconv3x3_bwd: sc needs sh (+mean/invstd for stats)");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  hipStream_t st = (hipStream_t)stream;
+  const int dw_mode = dw_fused_form(C, W, stride);
   if (gx && dw && stride == 1 && dw_mode != 0) {               // one pass: data gradient + statistics + weight-gradient partials
     const DwLayout l = dw_layout((int64_t)B * H * W, C);
     KD_REQUIRE(ws && ws_bytes >= (size_t)l.rows * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,
-                (float*)ws, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
+                (float*)ws, addend, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
     if (dw_mode == 2) {                     // tile form: l.rows slab rows (the row count the callers sized their slabs for) x channel chunks
       const int nchunk = (C + DT_CQ * 4 - 1) / (DT_CQ * 4);
       hipLaunchKernelGGL(dw_bwd_tile_s1_kernel, dim3((unsigned)l.rows * nchunk), dim3(256), 0, st, a, l.rows, nchunk);
-    } else
-    hipLaunchKernelGGL(dw_bwd_fused_s1_kernel, dim3(l.grid), dim3(256), 0, st, a);
+    } else if (addend) {
+      hipLaunchKernelGGL(dw_bwd_fused_s1_kernel<true>, dim3(l.grid), dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL(dw_bwd_fused_s1_kernel<false>, dim3(l.grid), dim3(256), 0, st, a);
+    }
     int rc = kd_check_launch("kd_dwconv3x3_bwd(fused)");
     if (rc) return rc;
     return kd_slab_reduce_launch((const float*)ws, l.rows, (int64_t)C * 9, dw, st);
@@ -1033,7 +1054,7 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
     const DwLayout l = dw_layout((int64_t)B * H * W, C);
     KD_REQUIRE(ws && ws_bytes >= (size_t)l.rows * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,
-                (float*)ws, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
+                (float*)ws, addend, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
     hipLaunchKernelGGL(dw_bwd_fused_s2_kernel, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(fused, stride 2)");
     if (rc) return rc;
@@ -1042,7 +1063,7 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
   if (gx) {
     const DwLayout l = dw_layout((int64_t)B * H * W, C);
     DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, sc ? partial : nullptr,
-                nullptr, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
+                nullptr, nullptr, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk, kd_nt_store((size_t)B * H * W * C * sizeof(float))};
     if (stride == 1) hipLaunchKernelGGL(dw_bwd_data_sw_kernel, dim3(l.grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dw_bwd_data_s2_kernel, dim3(l.grid), dim3(256), 0, st, a);
     int rc = kd_check_launch("kd_dwconv3x3_bwd(data)");
@@ -1051,7 +1072,7 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
   if (dw) {
     const DwLayout l = dw_layout((int64_t)B * Ho * Wo, C);
     KD_REQUIRE(ws && ws_bytes >= (size_t)l.rows * C * 9 * sizeof(float), KD_ERR_WORKSPACE, "kd_dwconv3x3_bwd: workspace too small");
-    DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, nullptr, nullptr, (float*)ws,
+    DwBwdArgs a{D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, nullptr, nullptr, (float*)ws, nullptr,
                 B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk, 0};
     if (stride == 1) hipLaunchKernelGGL(dw_bwd_weight_sw_kernel<1>, dim3(l.grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dw_bwd_weight_sw_kernel<2>, dim3(l.grid), dim3(256), 0, st, a);
@@ -1060,6 +1081,26 @@ int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const floa
     return kd_slab_reduce_launch((const float*)ws, l.rows, (int64_t)C * 9, dw, st);
   }
   return KD_OK;
+}
+
+int kd_dwconv3x3_bwd(const float* D, const float* Y, const float* al, const float* be, const float* ga,
+                     const float* dsc, const float* dsh, int d_act, const float* x, const float* sc, const float* sh,
+                     int act, const float* mean, const float* invstd, const float* w, float* gx, float* partial,
+                     float* dw, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream) {
+  return dw_bwd_impl(D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, partial, dw, nullptr, B, H, W, C, stride, ws,
+                     ws_bytes, stream);
+}
+
+// The same backward with a second gradient path into the conv's input -- the residual of an inverted-residual block whose
+// first convolution is this one (camera_encoder.py:46-51 with expansion_ratio 1) -- added to the data gradient before the
+// activation mask / BatchNorm-backward sums: gx = (conv^T dy + addend) * act'(.), one kernel instead of kernel + add pass.
+int kd_dwconv3x3_bwd_add(const float* D, const float* Y, const float* al, const float* be, const float* ga,
+                         const float* dsc, const float* dsh, int d_act, const float* x, const float* sc, const float* sh,
+                         int act, const float* mean, const float* invstd, const float* w, const float* addend, float* gx,
+                         float* partial, float* dw, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream) {
+  KD_REQUIRE(addend, KD_ERR_ARG, "kd_dwconv3x3_bwd_add: addend is NULL");
+  return dw_bwd_impl(D, Y, al, be, ga, dsc, dsh, d_act, x, sc, sh, act, mean, invstd, w, gx, partial, dw, addend, B, H, W, C, stride, ws,
+                     ws_bytes, stream);
 }
 
 int64_t kd_dwconv_bwd_stat_rows(int64_t npix_in, int C) { return dw_layout(npix_in, C).rows; }

@@ -17,6 +17,9 @@ from .losses import kd_objective, kd_objective_backward
 from .optim import FusedAdamW
 
 
+KD_FEATURES = ("camera_feat", "lidar_feat", "logits")       # what the objective reads of each model's intermediates
+
+
 class KDStep:
     def __init__(self, student, teacher, optimizer: FusedAdamW, class_weights: Optional[torch.Tensor] = None,
                  T: float = 4.0, alpha: float = 1.0, beta: float = 1.0, ignore_index: int = -1,
@@ -43,8 +46,8 @@ class KDStep:
         with torch.no_grad():
             if self.teacher_storage == "bf16":
                 from .bf16 import forward_bf16
-                return forward_bf16(self.teacher, images, points, return_intermediates=True)
-            return self.teacher(images, points, return_intermediates=True)
+                return forward_bf16(self.teacher, images, points, return_intermediates=KD_FEATURES)
+            return self.teacher(images, points, return_intermediates=KD_FEATURES)
 
     def objective_backward(self, zs, ms, zt, mt, labels):
         """Loss values + the student's backward pass -> (total, parts of detached device scalars)."""
@@ -62,7 +65,7 @@ class KDStep:
             gradsink.active = self.sink
             self.sink.begin_step()
             self.opt.zero_grad()
-            zs, ms = self.student(images, points, return_intermediates=True)
+            zs, ms = self.student(images, points, return_intermediates=KD_FEATURES)
         finally:
             units.share_point_bins(False)  # ... and nothing of it outlives the two forward passes
         total, parts = self.objective_backward(zs, ms, zt, mt, labels)
@@ -112,7 +115,7 @@ class GraphedKDStep:
         gradsink.active = s.sink
         s.sink.begin_step()
         s.opt.zero_grad()
-        zs, ms = s.student(self.images, self.points, return_intermediates=True)
+        zs, ms = s.student(self.images, self.points, return_intermediates=KD_FEATURES)
         total, parts = s.objective_backward(zs, ms, zt, mt, self.labels)
         s.opt.grad_scale = s.reducer.finish() if s.reducer is not None else 1.0
         s.opt.enqueue_update()

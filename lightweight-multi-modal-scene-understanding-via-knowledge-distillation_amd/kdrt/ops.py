@@ -409,9 +409,19 @@ def bn_act_apply(x, sc, sh, act, out, res=None):
     return out
 
 
-def materialize(op: Operand, res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+def materialize(op: Operand, res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                res_op: Optional[Operand] = None):
+    """act(bn(raw)) (+ res) as a plain [M, C] tensor; `res_op`: the residual as a deferred operand (applied on load)."""
     if out is None:
         out = torch.empty(op.M, op.C, device=op.raw.device, dtype=torch.float32)
+    if res_op is not None:
+        if res is not None:
+            raise KDError("materialize: give the residual as a tensor or as an operand, not both")
+        if res_op.bnc is None:
+            return bn_act_apply(op.raw, op.sc, op.sh, op.act, out, res_op.raw)
+        lib.call("kd_bn_act_apply_res", P(op.raw), ld(op.raw), P(op.sc), P(op.sh), op.act, P(res_op.raw), ld(res_op.raw),
+                 P(res_op.sc), P(res_op.sh), res_op.act, P(out), ld(out), op.M, op.C, stream())
+        return out
     return bn_act_apply(op.raw, op.sc, op.sh, op.act, out, res)
 
 

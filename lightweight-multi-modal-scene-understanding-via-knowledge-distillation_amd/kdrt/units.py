@@ -40,6 +40,14 @@ class _Rec:
     __slots__ = ("spec", "inp", "y", "bnc", "training", "out_geom", "w", "b", "gamma", "image")
 
 
+# KD_EVAL_COEFF_CACHE=0 recomputes the eval coefficients on every use (triage of a suspected stale cache).  Contract for code
+# that writes parameters or BatchNorm buffers behind torch's back -- `p.data.copy_()` bumps `_version` and is seen, but a raw
+# pointer write, `p.data = ...` re-pointing inside a kernel-side update, or a collective on `.data` is not: call
+# `kdrt.ops.bump_global_epoch()` afterwards (FusedAdamW, kd_bn_finalize_train, GraphedKDStep and the ddp broadcast do).
+_EVAL_COEFF_CACHE = os.environ.get("KD_EVAL_COEFF_CACHE", "1") != "0"
+_DW_BWD_ADD = os.environ.get("KD_DW_BWD_ADD", "1") != "0"        # 0: residual gradient of a depthwise-first block added by a separate pass
+
+
 def _coeffs(spec: UnitSpec, partial, rows, C, count, training, bnc=None, device=None):
     if training:
         bnc = bnc if bnc is not None else BNC(C, device)
@@ -54,7 +62,7 @@ def _coeffs(spec: UnitSpec, partial, rows, C, count, training, bnc=None, device=
     key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
            bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
            ops.bn_epoch(bn), ops.owner_epoch(bn.weight), ops.owner_epoch(bn.bias), ops.GLOBAL_EPOCH[0])
-    if bnc is None:
+    if bnc is None and _EVAL_COEFF_CACHE:
         hit = getattr(bn, "_kd_eval_cache", None)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -377,16 +385,24 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
             if deferred:
                 rows_in = lib.kd_dwconv_bwd_stat_rows(inp.M, C)
                 part_in = torch.empty(rows_in * 2 * C, device=dev, dtype=torch.float32)
-        lib.call("kd_dwconv3x3_bwd", P(t), P(y), P(al), P(be), P(ga), P(msc), P(msh), mact, P(inp.raw), P(inp.sc),
-                 P(inp.sh), inp.act, P(inp.bnc.mean) if deferred else None, P(inp.bnc.invstd) if deferred else None,
-                 P(rec.w), P(gx), P(part_in), P(dW), B, H, W, C, s, P(ws), nbytes, stream())
+        # a residual gradient into the same input rides inside the kernel where the one-pass form allows it (round 3)
+        add_in_kernel = (addend is not None and need_input_grad and _DW_BWD_ADD and ld(addend) == C
+                         and lib.kd_dwconv3x3_bwd_add_supported(C, W, s))
+        if add_in_kernel:
+            lib.call("kd_dwconv3x3_bwd_add", P(t), P(y), P(al), P(be), P(ga), P(msc), P(msh), mact, P(inp.raw), P(inp.sc),
+                     P(inp.sh), inp.act, P(inp.bnc.mean) if deferred else None, P(inp.bnc.invstd) if deferred else None,
+                     P(rec.w), P(addend), P(gx), P(part_in), P(dW), B, H, W, C, s, P(ws), nbytes, stream())
+        else:
+            lib.call("kd_dwconv3x3_bwd", P(t), P(y), P(al), P(be), P(ga), P(msc), P(msh), mact, P(inp.raw), P(inp.sc),
+                     P(inp.sh), inp.act, P(inp.bnc.mean) if deferred else None, P(inp.bnc.invstd) if deferred else None,
+                     P(rec.w), P(gx), P(part_in), P(dW), B, H, W, C, s, P(ws), nbytes, stream())
         if need_input_grad:
             if deferred:
-                if addend is not None:
-                    raise KDError("addend on a deferred depthwise input is not supported")
+                if addend is not None and not add_in_kernel:
+                    raise KDError("addend on a deferred depthwise input needs the one-pass stride-1 column-walk backward")
                 g_in = ("G", gx, part_in, rows_in)
             else:
-                if addend is not None:
+                if addend is not None and not add_in_kernel:
                     ops.bn_act_apply(gx, None, None, ACT_NONE, gx, res=addend)
                 g_in = gx
         grads = [gradsink.finish(rec.w, dW, w_dir)]
@@ -503,6 +519,68 @@ class ChainFn(torch.autograd.Function):
 
 def run_chain(x, units: Sequence[UnitSpec], residual: bool, training: bool):
     return ChainFn.apply(x, list(units), residual, run_mode(training), *_params_of(units))
+
+
+class PairChainFn(torch.autograd.Function):
+    """x -> chain A -> chain B (+ A's output: B is a residual block) with A's output never materialised: B's first unit and
+    B's residual connection read A's raw last output with its BatchNorm coefficients on load; in backward the residual
+    gradient enters B's first data-gradient kernel as an addend BEFORE the activation mask, so A receives a masked gradient
+    with its BatchNorm-backward sums already formed (no kd_bn_act_apply, no kd_bn_bwd_reduce over that tensor).
+    Stands in for: stem -> stage1 and stage2 -> stage3 of TwinLiteEncoder.forward (camera_encoder.py:98-104) in training."""
+
+    @staticmethod
+    def forward(ctx, x, units_a, units_b, training, *params):
+        training = training == 1
+        recs_a, recs_b = [], []
+        if units_a[0].kind == "stem":
+            ops.require_gpu_tensor(x, "TwinLiteEncoder")
+            cur = x
+        else:
+            xm, geom = ops.nhwc_view(x)
+            cur = Operand(xm, geom)
+        for u in units_a:
+            cur, rec = unit_forward(u, cur, training)
+            recs_a.append(rec)
+        mid = cur
+        for u in units_b:
+            cur, rec = unit_forward(u, cur, training)
+            recs_b.append(rec)
+        if cur.geom != mid.geom or cur.C != mid.C:
+            raise KDError("PairChainFn: the second chain is not a residual block over the first chain's output")
+        out = ops.materialize(cur, res_op=mid)
+        ctx.recs_a, ctx.recs_b = recs_a, recs_b
+        return ops.nchw_from_matrix(out, cur.geom)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dm, _ = ops.nhwc_view(dout)
+        grads_b, g = chain_backward(ctx.recs_b, ("D", dm), need_input_grad=True, first_addend=dm)
+        need = ctx.needs_input_grad[0] and ctx.recs_a[0].spec.kind != "stem"
+        grads_a, g_in = chain_backward(ctx.recs_a, g, need_input_grad=need)
+        dx = ops.nchw_from_matrix(g_in, ctx.recs_a[0].inp.geom) if need else None
+        return (dx, None, None, None, *grads_a, *grads_b)
+
+
+_CHAIN_PAIRS = os.environ.get("KD_CHAIN_PAIRS", "1") != "0"
+
+
+def chain_pair_ok(units_a: Sequence[UnitSpec], units_b: Sequence[UnitSpec], training: bool, out_w: int) -> bool:
+    """May A -> B run as one PairChainFn?  Training mode only; B's first unit must be able to take the residual gradient
+    inside its data-gradient kernel with a deferred input: any pointwise unit, a depthwise unit only in the stride-1
+    column-walk form (`out_w`: width of A's output map)."""
+    if not (_CHAIN_PAIRS and training and torch.is_grad_enabled()) or not units_a or not units_b:
+        return False
+    if units_a[-1].kind not in ("pw", "stem", "dw") or any(u.kind not in ("pw", "dw") for u in units_b):
+        return False
+    first = units_b[0]
+    if first.kind == "dw":
+        C = first.conv.weight.shape[0]
+        return bool(_DW_BWD_ADD and first.stride == 1 and lib.kd_dwconv3x3_bwd_add_supported(C, out_w, 1))
+    return True
+
+
+def run_chain_pair(x, units_a: Sequence[UnitSpec], units_b: Sequence[UnitSpec], training: bool):
+    return PairChainFn.apply(x, list(units_a), list(units_b), run_mode(training), *_params_of(units_a), *_params_of(units_b))
 
 
 # =================================================================================================
@@ -645,16 +723,17 @@ class ConcatFuseFn(torch.autograd.Function):
     marked non-differentiable."""
 
     @staticmethod
-    def forward(ctx, cam, lid, u_cam, u_lid, fuse_units, training, *params):
+    def forward(ctx, cam, lid, u_cam, u_lid, fuse_units, training, want_pre, *params):
         infer, training = training == 2, training == 1
         cat, comb, (op_c, rec_c), (op_l, rec_l), geom = _proj_pair(cam, lid, u_cam, u_lid, training)
         cur = Operand(cat, geom, comb, ACT_RELU)
-        pre = ops.materialize(cur)
+        # the activated concat buffer exists only for callers that ask for `pre_fusion` (a 2 GB pass at 256 frames otherwise
+        # paid by every forward: the fuse block itself reads the raw buffer with the BatchNorm coefficients on load)
+        pre_t = ops.nchw_from_matrix(ops.materialize(cur), geom) if want_pre else cat.new_empty(0)
+        ctx.mark_non_differentiable(pre_t)
         recs = []
         if inference_tail_ok(fuse_units, infer):
             out, ogeom = infer_tail(fuse_units, cur)
-            pre_t = ops.nchw_from_matrix(pre, geom)
-            ctx.mark_non_differentiable(pre_t)
             return ops.nchw_from_matrix(out, ogeom), pre_t
         for u in fuse_units:
             cur, rec = unit_forward(u, cur, training)
@@ -662,8 +741,6 @@ class ConcatFuseFn(torch.autograd.Function):
         out = ops.materialize(cur)
         ctx.rec_c, ctx.rec_l, ctx.recs = rec_c, rec_l, recs
         ctx.Cc, ctx.Cl = op_c.C, op_l.C
-        pre_t = ops.nchw_from_matrix(pre, geom)
-        ctx.mark_non_differentiable(pre_t)
         return ops.nchw_from_matrix(out, geom), pre_t
 
     @staticmethod
@@ -673,12 +750,13 @@ class ConcatFuseFn(torch.autograd.Function):
         _, gcat, partial, rows = g
         dcam, dlid, pg_c, pg_l = _proj_pair_backward(ctx, gcat, partial, rows, ctx.Cc, ctx.Cl,
                                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return (dcam, dlid, None, None, None, None, *pg_c, *pg_l, *fuse_grads)
+        return (dcam, dlid, None, None, None, None, None, *pg_c, *pg_l, *fuse_grads)
 
 
-def run_concat_fuse(cam, lid, u_cam, u_lid, fuse_units, training):
-    return ConcatFuseFn.apply(cam, lid, u_cam, u_lid, list(fuse_units), run_mode(training), *u_cam.params(), *u_lid.params(),
-                              *_params_of(fuse_units))
+def run_concat_fuse(cam, lid, u_cam, u_lid, fuse_units, training, want_pre=True):
+    """-> (fused, pre_fusion); pre_fusion is an empty tensor when `want_pre` is false."""
+    return ConcatFuseFn.apply(cam, lid, u_cam, u_lid, list(fuse_units), run_mode(training), bool(want_pre), *u_cam.params(),
+                              *u_lid.params(), *_params_of(fuse_units))
 
 
 class WeightedFuseFn(torch.autograd.Function):

@@ -69,14 +69,28 @@ class TwinLiteEncoder(nn.Module):
 
     def forward(self, x):
         stem = U.UnitSpec("stem", self.stem[0], self.stem[1], ACT_RELU6)
-        x0 = U.run_chain(x, [stem], False, self.training)
-        x1 = self.stage1(x0)
-        x2 = self.stage2(x1)
-        x3 = self.stage3(x2)
+        # Training: a block that feeds ONLY the residual block after it hands its output over un-materialised (PairChainFn):
+        # the stem -> stage1 always; stage2 -> stage3 unless somebody reads stage2's map (the owning model says which
+        # multiscale maps it uses through `unused_stages`; by default every map is produced, as in the reference).
+        w0 = (x.shape[-1] - 1) // 2 + 1
+        u1 = self.stage1._units()
+        if self.stage1.use_residual and U.chain_pair_ok([stem], u1, self.training, w0):
+            x1 = U.run_chain_pair(x, [stem], u1, self.training)
+        else:
+            x1 = self.stage1(U.run_chain(x, [stem], False, self.training))
+        x2 = None
+        u2, u3 = self.stage2._units(), self.stage3._units()
+        skip2 = (not self.return_multiscale) or "stage2" in getattr(self, "unused_stages", ())
+        if skip2 and self.stage3.use_residual and not self.stage2.use_residual and U.chain_pair_ok(u2, u3, self.training, 0):
+            x3 = U.run_chain_pair(x1, u2, u3, self.training)
+        else:
+            x2 = self.stage2(x1)
+            x3 = self.stage3(x2)
         x4 = self.stage4(x3)
         x5 = self.stage5(x4)
         if self.return_multiscale:
-            return {"stage2": x2, "stage3": x3, "stage4": x4, "stage5": x5}
+            maps = {"stage2": x2, "stage3": x3, "stage4": x4, "stage5": x5}
+            return {k: v for k, v in maps.items() if v is not None}
         return x5
 
     def get_feature_info(self):

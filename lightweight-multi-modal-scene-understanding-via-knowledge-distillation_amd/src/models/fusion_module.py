@@ -87,13 +87,13 @@ class ConcatenationFusion(nn.Module):
             nn.ReLU(), nn.Conv2d(in_cat, out_channels, kernel_size=1, bias=False), nn.BatchNorm2d(out_channels),
             nn.ReLU())
 
-    def run(self, cam_feat, lidar_feat):
+    def run(self, cam_feat, lidar_feat, want_pre=True):
         lidar_feat = _match_size(cam_feat, lidar_feat)
         return U.run_concat_fuse(cam_feat, lidar_feat, self.camera_proj.unit(), self.lidar_proj.unit(),
-                                 [_dw_unit(self.fuse, 0), _pw_unit(self.fuse, 3)], self.training)
+                                 [_dw_unit(self.fuse, 0), _pw_unit(self.fuse, 3)], self.training, want_pre)
 
     def forward(self, cam_feat, lidar_feat):
-        return self.run(cam_feat, lidar_feat)[0]
+        return self.run(cam_feat, lidar_feat, want_pre=False)[0]
 
 
 class MinimalFusion(nn.Module):
@@ -165,6 +165,8 @@ class CompleteSegmentationModel(nn.Module):
         if self.use_multiscale:
             self.camera_fpn = CameraFPNLite(in_channels_by_stage=camera_encoder.get_feature_info(),
                                             target_channels=camera_fpn_channels, stages_to_use=camera_fpn_stages)
+            # tell the encoder which multiscale maps nobody reads (it may then skip materialising them in training)
+            camera_encoder.unused_stages = tuple(s for s in camera_encoder.get_feature_info() if s not in self.camera_fpn.stages_to_use)
             cam_ch = camera_fpn_channels
         else:
             cam_ch = getattr(camera_encoder, "out_channels", 128)
@@ -187,18 +189,29 @@ class CompleteSegmentationModel(nn.Module):
         else:
             raise ValueError(f"Unknown output_mode: {output_mode}")
 
-    def forward(self, images: torch.Tensor, points: torch.Tensor, return_intermediates: bool = False):
+    def forward(self, images: torch.Tensor, points: torch.Tensor, return_intermediates=False):
+        """`return_intermediates`: the reference's bool (True: all five maps of fusion_module.py:260-262), or -- an extension --
+        a collection of their names, in which case only those are produced (the KD step asks for camera_feat / lidar_feat /
+        logits and so spares the concat block a 2 GB pass for a `pre_fusion` nobody reads)."""
+        names = None
+        if return_intermediates and not isinstance(return_intermediates, bool):
+            names = set(return_intermediates)
+            unknown = names - {"camera_feat", "lidar_feat", "pre_fusion", "post_fusion", "logits"}
+            if unknown:
+                raise ValueError(f"unknown intermediates {sorted(unknown)}")
         cam_raw = self.camera_encoder(images)
         cam_feat = self.camera_fpn(cam_raw) if isinstance(cam_raw, dict) else cam_raw
         lidar_feat = _match_size(cam_feat, self.lidar_encoder(points))       # fusion_module.py:238-240
         if isinstance(self.fusion, ConcatenationFusion):
-            fused, pre_fusion = self.fusion.run(cam_feat, lidar_feat)
+            want_pre = bool(return_intermediates) and (names is None or "pre_fusion" in names)
+            fused, pre_fusion = self.fusion.run(cam_feat, lidar_feat, want_pre=want_pre)
         else:
             fused = pre_fusion = self.fusion(cam_feat, lidar_feat)
         logits = self.head(fused)
         if return_intermediates:
-            return logits, {"camera_feat": cam_feat, "lidar_feat": lidar_feat, "pre_fusion": pre_fusion,
-                            "post_fusion": fused, "logits": logits}
+            mids = {"camera_feat": cam_feat, "lidar_feat": lidar_feat, "pre_fusion": pre_fusion,
+                    "post_fusion": fused, "logits": logits}
+            return logits, (mids if names is None else {k: v for k, v in mids.items() if k in names})
         return logits
 
     def get_architecture_summary(self):

@@ -356,6 +356,56 @@ def test_dw_stride1_backward_forms_agree(shape):
         assert ((wv - w0).abs().max() / w0.abs().max()).item() < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 13, 19, 8), (2, 40, 36, 32), (1, 17, 9, 48)])
+@pytest.mark.parametrize("deferred", (True, False))
+def test_dw_backward_with_residual_addend(shape, deferred):
+    """kd_dwconv3x3_bwd_add (the residual gradient of a depthwise-first inverted-residual block added inside the one-pass
+    backward, before the activation mask) against kd_dwconv3x3_bwd followed by the add: materialised input -- the sum, same
+    bits; deferred input -- (conv^T dy + addend) * act'(.) and the BatchNorm-backward sums of THAT, checked in float64."""
+    from kdrt.lib import lib
+    from kdrt.ops import P, stream, workspace
+    B, H, W, C = shape
+    assert lib.kd_dwconv3x3_bwd_add_supported(C, W, 1) == 1
+    M = B * H * W
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    D, Y, x, w, add = rnd(M, C), rnd(M, C), rnd(M, C), rnd(C, 9), rnd(M, C)
+    al, be, ga, sc, sh, mean = rnd(C), rnd(C) * 0.1, rnd(C) * 0.1, rnd(C).abs() + 0.5, rnd(C) * 0.2, rnd(C) * 0.1
+    inv = rnd(C).abs() + 0.5
+    rows = lib.kd_dwconv_bwd_stat_rows(M, C)
+    nbytes = lib.kd_dwconv_bwd_ws_bytes(M, C)
+    ws = workspace(nbytes, D.device)
+    d = (P(sc), P(sh), 2, P(mean), P(inv)) if deferred else (None, None, 0, None, None)
+
+    def run(addend):
+        gx = torch.full((M, C), float("nan"), device="cuda")
+        part = torch.full((rows * 2 * C,), float("nan"), device="cuda") if deferred else None
+        dw = torch.full((C, 9), float("nan"), device="cuda")
+        head = (P(D), P(Y), P(al), P(be), P(ga), None, None, 0, P(x), *d, P(w))
+        tail = (P(gx), P(part), P(dw), B, H, W, C, 1, P(ws), nbytes, stream())
+        if addend is None:
+            lib.call("kd_dwconv3x3_bwd", *head, *tail)
+        else:
+            lib.call("kd_dwconv3x3_bwd_add", *head, P(addend), *tail)
+        torch.cuda.synchronize()
+        return gx, (part.view(rows, 2, C).double().sum(0) if deferred else None), dw
+    gx0, _, dw0 = run(None) if not deferred else (None, None, None)
+    gx1, p1, dw1 = run(add)
+    if not deferred:
+        assert torch.equal(gx1, gx0 + add) and torch.equal(dw1, dw0)
+        return
+    # deferred: rebuild from the UNMASKED data gradient (plain-input call: same conv^T dy bits) in float64
+    d = (None, None, 0, None, None)
+    raw, _, dw0 = run(None)
+    z = x.double() * sc.double() + sh.double()
+    mask = ((z > 0) & (z < 6)).double()
+    want = (raw.double() + add.double()) * mask
+    assert (gx1.double() - want).abs().max().item() <= 1e-6 * want.abs().max().item()
+    xhat = (x.double() - mean.double()) * inv.double()
+    s1, s2 = want.sum(0), (want * xhat).sum(0)
+    assert ((p1[0] - s1).abs().max() / s1.abs().max()).item() < 1e-5 and ((p1[1] - s2).abs().max() / s2.abs().max()).item() < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(2, 13, 19, 8), (1, 70, 66, 72), (2, 32, 64, 192), (1, 9, 9, 384)])
 @pytest.mark.parametrize("deferred", (True, False))
 def test_dw_stride2_backward_forms_agree(shape, deferred):
@@ -467,3 +517,42 @@ def test_dw_pw_inference_fusion_refuses_unsupported_shapes():
     with pytest.raises(KDError):
         lib.call("kd_dw_pw_infer", P(x), None, None, 0, P(w), P(v), P(v), 1, P(w), None, P(v), P(v), 1, None, 0, P(out), 96, 1, 8, 8, 48, 1, 96,
                  stream())
+
+
+def test_chain_pairs_match_separate_chains(monkeypatch):
+    """stem -> stage1 and stage2 -> stage3 as PairChainFn (the first block's output never materialised: read raw with its
+    BatchNorm coefficients by the second block's first convolution AND by its residual connection; the residual gradient
+    folded into that convolution's data-gradient kernel before the activation mask) against the separate chains: the same
+    forward bits, gradients to summation order (the BatchNorm-backward sums come from different kernels)."""
+    from kdrt import units
+    from src.models.camera_encoder import TwinLiteEncoder
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 96, 80, device="cuda")
+    up = None
+    res = {}
+    for pairs in (True, False):
+        monkeypatch.setattr(units, "_CHAIN_PAIRS", pairs)
+        enc = TwinLiteEncoder(return_multiscale=True)
+        enc.unused_stages = ("stage2",)
+        _rand_state(enc, 17)
+        enc = enc.cuda().train()
+        maps = enc(x)
+        assert ("stage2" in maps) == (not pairs)
+        if up is None:
+            up = {k: torch.randn(v.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) for k, v in maps.items()}
+        sum((maps[k] * up[k]).sum() for k in ("stage3", "stage4", "stage5")).backward()
+        torch.cuda.synchronize()
+        res[pairs] = ({k: maps[k].detach().clone() for k in ("stage3", "stage4", "stage5")},
+                      {n: p.grad.detach().clone() for n, p in enc.named_parameters()},
+                      {n: b.detach().clone() for n, b in enc.named_buffers()})
+    (m1, g1, b1), (m0, g0, b0) = res[True], res[False]
+    for k in m0:
+        assert torch.equal(m1[k].view(torch.int32), m0[k].view(torch.int32)), k
+    for n in b0:
+        assert torch.equal(b1[n], b0[n]), n                      # running statistics: same forward, same bits
+    # (a BatchNorm shift that feeds another training-mode BatchNorm has a mathematically ZERO gradient -- what both runs hold
+    # there is the rounding residue of a million-term sum, so the floor of the comparison is the largest gradient in the model)
+    gmax = max(v.abs().max().item() for v in g0.values())
+    for n in g0:
+        scale = max(g0[n].abs().max().item(), 1e-2 * gmax)
+        assert (g1[n] - g0[n]).abs().max().item() <= 2e-5 * scale, (n, (g1[n] - g0[n]).abs().max().item(), scale)

@@ -15,12 +15,18 @@ def family(k):
         return "pw_gemm+pw_stream"
     if "pw_wgrad_kernel" in k:
         return "pw_wgrad_kernel"
+    if "lidar_l2_bwd_kernel" in k or "lidar_l1_bwd_kernel" in k:
+        return "lidar_bwd"
+    if "lidar_mlp_scatter_infer" in k:
+        return "lidar_infer"
+    if "dw_fwd" in k or "dw_bwd" in k:
+        return "depthwise"
     return None
 
 
 def load(d, name):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(glob.glob(d + "/*/*_counter_collection.csv")[0])):
+    for r in csv.DictReader(open((glob.glob(d + "/*/*_counter_collection.csv") + glob.glob(d + "/*_counter_collection.csv"))[0])):
         if r["Counter_Name"] != name:
             continue
         fam = family(r["Kernel_Name"])
@@ -32,7 +38,9 @@ def load(d, name):
 
 fe, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 res = {}
-for fam in ("pw_gemm+pw_stream", "pw_wgrad_kernel"):
+for fam in ("pw_gemm+pw_stream", "pw_wgrad_kernel", "lidar_bwd", "lidar_infer", "depthwise"):
+    if fam not in fe:
+        continue
     n = fe[fam][0]
     assert n == wr[fam][0] and n > 0, (fam, fe[fam], wr[fam])
     f = fe[fam][1] * 1024 * 2 / n
