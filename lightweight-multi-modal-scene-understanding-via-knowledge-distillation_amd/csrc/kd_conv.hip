@@ -363,6 +363,8 @@ template <bool ADD>
 __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
   __shared__ float red[2 * 256 * 4];
   __shared__ __attribute__((aligned(16))) float wl[9 * 1024];   // flipped taps, [tap][channel]: wl[t][c] = w[c][8 - t] (C <= 1024)
+  // ADD: the input BatchNorm's mean / invstd live in LDS too (the addend's registers would otherwise push the kernel into scratch)
+  __shared__ __attribute__((aligned(16))) float cf[ADD ? 2 * 1024 : 4];
   const int tid = threadIdx.x;
   const int gidx = tid % a.groups, slot = tid / a.groups;
   const bool active = slot < a.slots;
@@ -373,6 +375,8 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) wacc[t] = kd_zero4();
   for (int i = tid; i < a.C * 9; i += 256) wl[(i % 9) * a.C + i / 9] = a.w[(i / 9) * 9 + (8 - i % 9)];
+  if (ADD)
+    for (int i = tid; i < a.C; i += 256) { cf[i] = a.mean ? a.mean[i] : 0.f; cf[1024 + i] = a.mean ? a.invstd[i] : 0.f; }
   __syncthreads();
   // (the nine taps live in LDS, not in 36 registers: with the dy window, the input window, the weight-gradient
   // accumulators and the one-row-ahead prefetch the kernel would otherwise spill)
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
     if (a.dsc) { dsc = kd_ld4(a.dsc + c0); dsh = kd_ld4(a.dsh + c0); }
     const bool deferred = a.sc != nullptr;
     if (deferred) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
-    if (a.mean) { mean = kd_ld4(a.mean + c0); inv = kd_ld4(a.invstd + c0); }
+    if (!ADD && a.mean) { mean = kd_ld4(a.mean + c0); inv = kd_ld4(a.invstd + c0); }
     const int nseg = (a.H + DW_SEG - 1) / DW_SEG;
     const int64_t items = (int64_t)a.B * nseg * a.W;
     for (int64_t it = (int64_t)bx * a.slots + slot; it < items; it += (int64_t)nbx * a.slots) {
@@ -402,10 +406,11 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
       // hi + 1 and the raw input row hi are requested before the store of row hi - 1 is issued.
       DwRaw nl = dw_dy_raw_s1(a, b, h0 + 1, wi - 1, c0), nc = dw_dy_raw_s1(a, b, h0 + 1, wi, c0), nr = dw_dy_raw_s1(a, b, h0 + 1, wi + 1, c0);
       DwRow xn = dw_load_row_raw(a.x, b, h0, wi, a.H, a.W, a.C, c0);
-      float4 adn = kd_zero4();
-      if (ADD) adn = kd_ld4(a.addend + (((int64_t)b * a.H + h0) * a.W + wi) * a.C + c0);
       for (int hi = h0; hi < h1; ++hi) {
-        const float4 ad = adn;
+        // the residual addend of THIS row: requested first, i.e. older than the next-row prefetches below, so that waiting for
+        // it near the end of the iteration leaves those in flight (a row-ahead copy of it would cost the registers that spill)
+        float4 ad = kd_zero4();
+        if (ADD) ad = kd_ld4(a.addend + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0);
         {
           const bool hok = hi + 1 < a.Ho;
           r2.l = dw_dy_finish(a, nl, hok && wi - 1 >= 0, al, be, ga, dsc, dsh);
@@ -416,7 +421,6 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
         const DwRow xa = dw_finish_row(xn, deferred, sc, sh, a.act, hi, wi, a.H, a.W);
         nl = dw_dy_raw_s1(a, b, hi + 2, wi - 1, c0); nc = dw_dy_raw_s1(a, b, hi + 2, wi, c0); nr = dw_dy_raw_s1(a, b, hi + 2, wi + 1, c0);
         xn = dw_load_row_raw(a.x, b, hi + 1 < a.H ? hi + 1 : hi, wi, a.H, a.W, a.C, c0);
-        if (ADD) adn = kd_ld4(a.addend + (((int64_t)b * a.H + (hi + 1 < a.H ? hi + 1 : hi)) * a.W + wi) * a.C + c0);
         // ---- weight gradient.  dw[kh][kw] = sum_ho dy(ho) x(ho - 1 + kh, wo - 1 + kw): the input row hi pairs with the dy
         // centres of rows hi + 1 (kh = 0), hi (kh = 1), hi - 1 (kh = 2), all three in the dy window (zero outside the image),
         // so no input window is kept: every input row is activated once and used once. ---------------------------------
@@ -441,6 +445,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_s1_kernel(DwBwdArgs a) {
           acc.y *= kd_act_mask(kd_affine(xr.y, sc.y, sh.y), a.act);
           acc.z *= kd_act_mask(kd_affine(xr.z, sc.z, sh.z), a.act);
           acc.w *= kd_act_mask(kd_affine(xr.w, sc.w, sh.w), a.act);
+          if (ADD) { mean = kd_ld4(cf + c0); inv = kd_ld4(cf + 1024 + c0); }
           s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
           s2.x = fmaf(acc.x, (xr.x - mean.x) * inv.x, s2.x);
           s2.y = fmaf(acc.y, (xr.y - mean.y) * inv.y, s2.y);
