@@ -82,6 +82,48 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
   }
 }
 
+// Round 3 form (as stem_fwd2_kernel in kd_conv.hip): the pixel's 9 * CIN inputs first, then one fma chain per output channel with
+// the weights as wave-uniform scalar loads (no LDS, no per-fma ds_read; the first form needed 256 VGPRs + 66 AGPRs at one wave/SIMD).
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_bf16_v2_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sc,
+                                                           const float* __restrict__ sh, int act, bf16_t* __restrict__ y, int B, int H, int W,
+                                                           int Ho, int Wo) {
+  constexpr int KK = CIN * 9;
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), b = (int)(p / ((int64_t)Wo * Ho));
+    float v[KK];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      const float* xp = x + ((int64_t)b * CIN + ci) * H * W;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hi = 2 * ho - 1 + kh;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int wi = 2 * wo - 1 + kw;
+          const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+          const float t = xp[(int64_t)(ok ? hi : 0) * W + (ok ? wi : 0)];
+          v[ci * 9 + kh * 3 + kw] = ok ? t : 0.f;
+        }
+      }
+    }
+    bf16_t* yp = y + p * 32;
+#pragma unroll
+    for (int c = 0; c < 32; c += 8) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < KK; ++t) acc = fmaf(v[t], w[(c + j) * KK + t], acc);
+        o[j] = kd_act(kd_affine(acc, sc[c + j], sh[c + j]), act);
+      }
+      st16(yp + c, pack8(o));
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // depthwise 3x3 (stride 1 / 2, pad 1) on an ACTIVATED bf16 input; output act(conv * scale + shift) as bf16.
 // A thread owns 8 channels (16 bytes) of a column segment and slides a 3-row window down it; taps in LDS ([tap][C]).
@@ -460,8 +502,10 @@ int kd_bf16_stem(const float* x_nchw, const float* w, const float* sc, const flo
   const int64_t npix = (int64_t)B * Ho * Wo;
   int64_t grid = (npix + 255) / 256;
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(stem_bf16_kernel, dim3((unsigned)grid), dim3(256), (size_t)Cin * 9 * 32 * sizeof(float), (hipStream_t)stream, x_nchw, w, sc,
-                     sh, act, (bf16_t*)y, B, Cin, H, W, Ho, Wo);
+  if (Cin == 3) hipLaunchKernelGGL(stem_bf16_v2_kernel<3>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w, sc, sh, act,
+                                   (bf16_t*)y, B, H, W, Ho, Wo);
+  else hipLaunchKernelGGL(stem_bf16_kernel, dim3((unsigned)grid), dim3(256), (size_t)Cin * 9 * 32 * sizeof(float), (hipStream_t)stream, x_nchw, w, sc,
+                          sh, act, (bf16_t*)y, B, Cin, H, W, Ho, Wo);
   return kd_check_launch("kd_bf16_stem");
 }
 

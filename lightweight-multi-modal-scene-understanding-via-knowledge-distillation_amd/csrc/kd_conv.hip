@@ -73,6 +73,80 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   }
 }
 
+// Round 3 form of the same convolution (same fma chain per output channel, bit-identical raw output): the 9 * CIN input values
+// of a pixel are fetched first (independent loads), then every output channel is one fma chain whose weights are wave-uniform
+// constants-offset reads of `w` -- scalar loads into SGPRs (s_load_dwordx*), no LDS and no per-fma ds_read; BatchNorm sums are
+// kept per thread in registers over all of the thread's pixels and reduced once at the end of the kernel (the first form
+// staged every 256-pixel batch through LDS and let 64 threads add 256 values each).
+template <int CIN, bool STATS>
+__global__ __launch_bounds__(256) void stem_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ y, float* __restrict__ partial, int B, int H, int W,
+                                                        int Ho, int Wo) {
+  constexpr int KK = CIN * 9;
+  __shared__ float red[STATS ? 256 * 33 : 1];
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  float s1[STATS ? 32 : 1], s2[STATS ? 32 : 1];
+#pragma unroll
+  for (int c = 0; c < (STATS ? 32 : 1); ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < npix; base += (int64_t)gridDim.x * 256) {
+    const int64_t p = base + threadIdx.x;
+    if (p < npix) {
+      const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), b = (int)(p / ((int64_t)Wo * Ho));
+      float v[KK];
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        const float* xp = x + ((int64_t)b * CIN + ci) * H * W;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int hi = 2 * ho - 1 + kh;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int wi = 2 * wo - 1 + kw;
+            const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+            const float t = xp[(int64_t)(ok ? hi : 0) * W + (ok ? wi : 0)];
+            v[ci * 9 + kh * 3 + kw] = ok ? t : 0.f;
+          }
+        }
+      }
+      float* yp = y + p * 32;
+#pragma unroll
+      for (int c4 = 0; c4 < 32; c4 += 4) {
+        float a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float acc = 0.f;
+#pragma unroll
+          for (int t = 0; t < KK; ++t) acc = fmaf(v[t], w[(c4 + j) * KK + t], acc);
+          a[j] = acc;
+          if (STATS) { s1[c4 + j] += acc; s2[c4 + j] = fmaf(acc, acc, s2[c4 + j]); }
+        }
+        kd_st4(yp + c4, make_float4(a[0], a[1], a[2], a[3]));
+      }
+    }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 32; ++c) red[threadIdx.x * 33 + c] = st ? s2[c] : s1[c];
+      __syncthreads();
+      const int c = threadIdx.x & 31, seg = threadIdx.x >> 5;            // 8 segments of 32 threads' sums per channel
+      float s = 0.f;
+      for (int r = 0; r < 32; ++r) s += red[(seg * 32 + r) * 33 + c];
+      __syncthreads();
+      red[seg * 33 + c] = s;
+      __syncthreads();
+      if (threadIdx.x < 32) {
+        float tot = 0.f;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) tot += red[g8 * 33 + threadIdx.x];
+        partial[((int64_t)blockIdx.x * 2 + st) * 32 + threadIdx.x] = tot;
+      }
+    }
+  }
+}
+
 // im2col of the stem input, K padded 27 -> 32 (zeros): col[p][ci*9+kh*3+kw].  Only used by the
 // stem weight gradient, which then is the ordinary TN wgrad GEMM with K = 32.
 __global__ void stem_im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int Cin, int H, int W,
@@ -975,8 +1049,15 @@ int kd_stem_conv_fwd(const float* x_nchw, const float* w, float* y_nhwc, float* 
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int64_t npix = (int64_t)B * Ho * Wo;
   const int grid = (int)kd_stem_stat_rows(npix);
+  hipStream_t st = (hipStream_t)stream;
+  static const bool old_form = getenv("KD_STEM_FORM") && atoi(getenv("KD_STEM_FORM")) == 1;      // A/B: the LDS-weights form of rounds 1-2
+  if (Cin == 3 && !old_form) {
+    if (partial) hipLaunchKernelGGL((stem_fwd2_kernel<3, true>), dim3(grid), dim3(256), 0, st, x_nchw, w, y_nhwc, partial, B, H, W, Ho, Wo);
+    else hipLaunchKernelGGL((stem_fwd2_kernel<3, false>), dim3(grid), dim3(256), 0, st, x_nchw, w, y_nhwc, partial, B, H, W, Ho, Wo);
+    return kd_check_launch("kd_stem_conv_fwd");
+  }
   const size_t shm = (size_t)(Cin * 9 * 32 + 256 * 33) * sizeof(float);
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), shm, (hipStream_t)stream, x_nchw, w, y_nhwc, partial, B,
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), shm, st, x_nchw, w, y_nhwc, partial, B,
                      Cin, H, W, Ho, Wo);
   return kd_check_launch("kd_stem_conv_fwd");
 }
