@@ -89,8 +89,16 @@ __global__ __launch_bounds__(256) void stem_bf16_v2_kernel(const float* __restri
                                                            const float* __restrict__ sh, int act, bf16_t* __restrict__ y, int B, int H, int W,
                                                            int Ho, int Wo) {
   constexpr int KK = CIN * 9;
+  // a pixel = 64 contiguous output bytes per thread: through a wave-private LDS tile (rows padded to 80 bytes) so that the wave
+  // leaves four fully coalesced 1 KB stores instead of four stores that touch 64 lines each (as stem_fwd2_kernel)
+  constexpr int TLD = 40;                                                      // bf16 per tile row
+  __shared__ __attribute__((aligned(16))) bf16_t tiles[4 * 64 * TLD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bf16_t* tile = tiles + wave * 64 * TLD;
   const int64_t npix = (int64_t)B * Ho * Wo;
-  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < npix; base += (int64_t)gridDim.x * 256) {
+    const int64_t p_raw = base + threadIdx.x;
+    const int64_t p = p_raw < npix ? p_raw : npix - 1;
     const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), b = (int)(p / ((int64_t)Wo * Ho));
     float v[KK];
 #pragma unroll
@@ -108,7 +116,6 @@ __global__ __launch_bounds__(256) void stem_bf16_v2_kernel(const float* __restri
         }
       }
     }
-    bf16_t* yp = y + p * 32;
 #pragma unroll
     for (int c = 0; c < 32; c += 8) {
       float o[8];
@@ -119,8 +126,17 @@ __global__ __launch_bounds__(256) void stem_bf16_v2_kernel(const float* __restri
         for (int t = 0; t < KK; ++t) acc = fmaf(v[t], w[(c + j) * KK + t], acc);
         o[j] = kd_act(kd_affine(acc, sc[c + j], sh[c + j]), act);
       }
-      st16(yp + c, pack8(o));
+      st16(tile + lane * TLD + c, pack8(o));
     }
+    __builtin_amdgcn_wave_barrier();                            // (LDS is in-order per wave; this only pins the compiler's order)
+    const int64_t wbase = base + wave * 64;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pix = 16 * k + (lane >> 2), col = (lane & 3) * 8;
+      const u32x4 o = ld16(tile + pix * TLD + col);
+      if (wbase + pix < npix) st16(y + (wbase + pix) * 32 + col, o);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

@@ -78,19 +78,33 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 // constants-offset reads of `w` -- scalar loads into SGPRs (s_load_dwordx*), no LDS and no per-fma ds_read; BatchNorm sums are
 // kept per thread in registers over all of the thread's pixels and reduced once at the end of the kernel (the first form
 // staged every 256-pixel batch through LDS and let 64 threads add 256 values each).
+// timing-only probes of dev builds (-DKD_STEM_PROBE=bits; results WRONG by construction): 1 no stores, 2 no input loads, 4 a quarter of the channels
+#ifndef KD_STEM_PROBE
+#define KD_STEM_PROBE 0
+#endif
 template <int CIN, bool STATS>
 __global__ __launch_bounds__(256) void stem_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         float* __restrict__ y, float* __restrict__ partial, int B, int H, int W,
                                                         int Ho, int Wo) {
   constexpr int KK = CIN * 9;
-  __shared__ float red[STATS ? 256 * 33 : 1];
+  // A thread owns one pixel = 128 contiguous output bytes; stored straight from its registers that is eight 16-byte stores whose
+  // 64 lanes hit 64 different lines each (probe: 357 us with the stores, 72 us without: 1.9 TB/s).  So a wave's 64 x 32 results
+  // go through a wave-private LDS tile (rows padded to 36 floats: aligned 16-byte accesses in both directions) and leave as eight
+  // fully coalesced 1 KB stores: lane l writes bytes [16 l, 16 l + 16) of each KB.  The tile doubles as the statistics staging.
+  constexpr int TLD = 36;
+  __shared__ __attribute__((aligned(16))) float red[4 * 64 * TLD];
+  static_assert(4 * 64 * TLD >= 256 * 33, "the end-of-kernel statistics reduction reuses the tile");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* tile = red + wave * 64 * TLD;
   const int64_t npix = (int64_t)B * Ho * Wo;
   float s1[STATS ? 32 : 1], s2[STATS ? 32 : 1];
 #pragma unroll
   for (int c = 0; c < (STATS ? 32 : 1); ++c) { s1[c] = 0.f; s2[c] = 0.f; }
   for (int64_t base = (int64_t)blockIdx.x * 256; base < npix; base += (int64_t)gridDim.x * 256) {
-    const int64_t p = base + threadIdx.x;
-    if (p < npix) {
+    const int64_t p_raw = base + threadIdx.x;
+    const bool pok = p_raw < npix;
+    const int64_t p = pok ? p_raw : npix - 1;                  // (tail lanes recompute the last pixel; nothing of it is stored or summed)
+    {
       const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), b = (int)(p / ((int64_t)Wo * Ho));
       float v[KK];
 #pragma unroll
@@ -103,14 +117,13 @@ __global__ __launch_bounds__(256) void stem_fwd2_kernel(const float* __restrict_
           for (int kw = 0; kw < 3; ++kw) {
             const int wi = 2 * wo - 1 + kw;
             const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
-            const float t = xp[(int64_t)(ok ? hi : 0) * W + (ok ? wi : 0)];
+            const float t = (KD_STEM_PROBE & 2) ? (float)(hi + wi) : xp[(int64_t)(ok ? hi : 0) * W + (ok ? wi : 0)];
             v[ci * 9 + kh * 3 + kw] = ok ? t : 0.f;
           }
         }
       }
-      float* yp = y + p * 32;
 #pragma unroll
-      for (int c4 = 0; c4 < 32; c4 += 4) {
+      for (int c4 = 0; c4 < ((KD_STEM_PROBE & 4) ? 8 : 32); c4 += 4) {
         float a[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -118,11 +131,20 @@ __global__ __launch_bounds__(256) void stem_fwd2_kernel(const float* __restrict_
 #pragma unroll
           for (int t = 0; t < KK; ++t) acc = fmaf(v[t], w[(c4 + j) * KK + t], acc);
           a[j] = acc;
-          if (STATS) { s1[c4 + j] += acc; s2[c4 + j] = fmaf(acc, acc, s2[c4 + j]); }
+          if (STATS) { const float q = pok ? acc : 0.f; s1[c4 + j] += q; s2[c4 + j] = fmaf(q, q, s2[c4 + j]); }
         }
-        kd_st4(yp + c4, make_float4(a[0], a[1], a[2], a[3]));
+        kd_st4(tile + lane * TLD + c4, make_float4(a[0], a[1], a[2], a[3]));
       }
     }
+    __builtin_amdgcn_wave_barrier();                            // (LDS is in-order per wave; this only pins the compiler's order)
+    const int64_t wbase = base + wave * 64;                     // first pixel of this wave's 64
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int pix = 8 * k + (lane >> 3), col = (lane & 7) * 4;
+      const float4 o = kd_ld4(tile + pix * TLD + col);
+      if (!(KD_STEM_PROBE & 1) && wbase + pix < npix) kd_st4(y + (wbase + pix) * 32 + col, o);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   if (STATS) {
 #pragma unroll
@@ -164,6 +186,53 @@ __global__ void stem_im2col_kernel(const float* __restrict__ x, float* __restric
     if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = x[(((int64_t)b * Cin + ci) * H + hi) * W + wi];
   }
   col[i] = v;
+}
+
+// Round 3 form for Kp == 32: one thread gathers the 9 * CIN inputs of a pixel (instead of one thread per matrix element, whose
+// index arithmetic cost more than its load) and the wave leaves its 64 x 32 block through the same wave-private LDS tile as
+// stem_fwd2_kernel: eight coalesced 1 KB stores.
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_im2col2_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int H, int W, int Ho, int Wo) {
+  constexpr int KK = CIN * 9, TLD = 36;
+  static_assert(KK <= 32, "K is padded to 32");
+  __shared__ __attribute__((aligned(16))) float tiles[4 * 64 * TLD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* tile = tiles + wave * 64 * TLD;
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < npix; base += (int64_t)gridDim.x * 256) {
+    const int64_t p_raw = base + threadIdx.x;
+    const int64_t p = p_raw < npix ? p_raw : npix - 1;
+    const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), b = (int)(p / ((int64_t)Wo * Ho));
+    float v[32];
+#pragma unroll
+    for (int t = KK; t < 32; ++t) v[t] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      const float* xp = x + ((int64_t)b * CIN + ci) * H * W;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hi = 2 * ho - 1 + kh;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int wi = 2 * wo - 1 + kw;
+          const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+          const float t = xp[(int64_t)(ok ? hi : 0) * W + (ok ? wi : 0)];
+          v[ci * 9 + kh * 3 + kw] = ok ? t : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int c4 = 0; c4 < 32; c4 += 4) kd_st4(tile + lane * TLD + c4, make_float4(v[c4], v[c4 + 1], v[c4 + 2], v[c4 + 3]));
+    __builtin_amdgcn_wave_barrier();
+    const int64_t wbase = base + wave * 64;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int pix = 8 * k + (lane >> 3), c = (lane & 7) * 4;
+      const float4 o = kd_ld4(tile + pix * TLD + c);
+      if (wbase + pix < npix) kd_st4(col + (wbase + pix) * 32 + c, o);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -999,9 +1068,8 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_sw_kernel(DwBwdArgs a) {
 
 }  // namespace
 
-// stride-1 backward form: 0 separate data / weight kernels, 1 fused column walk, 2 fused tile form, 3 (default) by shape:
-// measured on an MI355X (tools/bench_dw, 32 frames) the tile form wins on wide maps with many channels (384 ch at 64x64:
-// 283 vs 330 us), ties at 128-256 channels and loses on 32x32 maps (768 ch: 257 vs 238 us).  KD_DW_FUSED / kd_set_dw_bwd_mode.
+// stride-1 backward form: 0 separate data / weight kernels, 1 fused column walk, 2 fused tile form, 3 (default) by shape
+// (dw_fused_form below: the measurements behind the choice).  KD_DW_FUSED / kd_set_dw_bwd_mode.
 static std::atomic<int> g_dw_mode{-1};
 static int kd_dw_fused_mode() {
   int m = g_dw_mode.load(std::memory_order_relaxed);
@@ -1066,6 +1134,12 @@ int kd_stem_im2col(const float* x_nchw, float* col, int B, int Cin, int H, int W
   KD_REQUIRE(x_nchw && col && Kp >= Cin * 9 && Kp % 4 == 0, KD_ERR_ARG, "kd_stem_im2col: bad args");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int64_t n = (int64_t)B * Ho * Wo * Kp;
+  if (Cin == 3 && Kp == 32 && kd_aligned16(col)) {
+    int64_t grid = ((int64_t)B * Ho * Wo + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(stem_im2col2_kernel<3>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, col, B, H, W, Ho, Wo);
+    return kd_check_launch("kd_stem_im2col");
+  }
   hipLaunchKernelGGL(stem_im2col_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_nchw,
                      col, B, Cin, H, W, Ho, Wo, Kp);
   return kd_check_launch("kd_stem_im2col");

@@ -162,6 +162,7 @@ def get_gemm_arithmetic() -> str:
 
 
 import os as _os
+import weakref as _weakref
 set_gemm_arithmetic(_os.environ.get("KD_GEMM", "split"))     # default: the faster fp32-grade arithmetic; KD_GEMM=fp32 selects exact products
 
 PROFILE = None      # bench.py sets this to a list to time GEMM launches with HIP events on the launch stream
@@ -343,14 +344,15 @@ class TransposeCache:
     hipGraph that contains the refresh launch and their readers replays correctly."""
 
     def __init__(self):
-        self.entries = {}          # (data_ptr, R, C) -> [weight view, W^T buffer, stamp, owning parameter]
+        self.entries = {}          # (data_ptr, R, C) -> [weight view, W^T buffer, stamp, weakref to the owning parameter]
         self.table = None
         self.nblocks = 0
         self.enabled = _os.environ.get("KD_TRANSPOSE_CACHE", "1") != "0"
 
     @staticmethod
     def _stamp(e):
-        return (GLOBAL_EPOCH[0], owner_epoch(e[3]), e[3]._version)
+        o = e[3]()
+        return None if o is None else (GLOBAL_EPOCH[0], owner_epoch(o), o._version)
 
     def get(self, w2d, owner):
         if not self.enabled or owner is None:
@@ -361,14 +363,21 @@ class TransposeCache:
             if torch.cuda.is_current_stream_capturing():
                 return None
             R, Cc = w2d.shape
-            self.entries[key] = [w2d.detach(), torch.empty(Cc, R, device=w2d.device, dtype=torch.float32), None, owner]
+            self.entries[key] = [w2d.detach(), torch.empty(Cc, R, device=w2d.device, dtype=torch.float32), None, _weakref.ref(owner)]
             self.table = None
             return None
-        return e[1] if e[2] == self._stamp(e) else None
+        return e[1] if (e[2] is not None and e[2] == self._stamp(e)) else None
 
     def refresh(self):
         if not self.enabled or not self.entries:
             return
+        dead = [k for k, e in self.entries.items() if e[3]() is None]          # models that are gone: stop refreshing their weights
+        if dead and not torch.cuda.is_current_stream_capturing():
+            for k in dead:
+                del self.entries[k]
+            self.table = None
+            if not self.entries:
+                return
         ents = list(self.entries.values())
         if self.table is None:
             rows, blk = [], 0
