@@ -599,7 +599,15 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / (WN * WK), wn = (wave % (WN * WK)) / WK, wk = wave % WK;
   const int ntn = (g.N + TN - 1) / TN, ntk = (g.K + TK - 1) / TK;
-  const int tile = blockIdx.x % (ntn * ntk), split = blockIdx.x / (ntn * ntk);
+  // XCD-aware order (speed only, as in pw_gemm_kernel): blocks b, b + 8, b + 16, ... share an L2, so THEY get the ntn * ntk output
+  // tiles of one row slice -- its D / A rows then come from HBM once and from that XCD's L2 for the other tiles (round 3; PMC
+  // before: the weight-gradient family moved 1.25x its algorithmic bytes, blockIdx % ntiles having dealt a slice's tiles over all XCDs)
+  int tile, split;
+  {
+    const int ntiles = ntn * ntk, nsl = (int)gridDim.x / ntiles, grp = 8 * ntiles, g0 = (int)blockIdx.x / grp, r = (int)blockIdx.x % grp;
+    if ((g0 + 1) * 8 <= nsl) { split = g0 * 8 + (r & 7); tile = r >> 3; }
+    else { const int rem = nsl - g0 * 8; split = g0 * 8 + r % rem; tile = r / rem; }
+  }
   const int n0 = (tile / ntk) * TN, k0 = (tile % ntk) * TK;
   const int64_t mbeg = (int64_t)split * g.rows_per_split;
   int64_t mend = mbeg + g.rows_per_split;
