@@ -108,3 +108,23 @@ def test_label_grid_that_does_not_match_the_logits_is_refused():
         seg_loss(z, torch.zeros(2, 8, 8, dtype=torch.int64, device="cuda"))
     with pytest.raises(KDError):
         seg_loss(z, torch.zeros(2, 16, 16, dtype=torch.int64))
+
+
+def test_return_intermediates_by_name():
+    """`return_intermediates` also takes a collection of names (the KD step's three maps): the same tensors, bit for bit, as the
+    reference's bool form, and the concat block then skips materialising `pre_fusion`."""
+    B, HW, N, G = 2, 64, 700, 16
+    images, pts, _ = O.make_inputs(B, HW, N, G, 4, pad_tail=40)
+    m = build_product("concat", G)
+    load_random_state(m, "concat", 11)
+    m.eval()
+    with torch.no_grad():
+        z_all, mids_all = m(images.cuda(), pts.cuda(), return_intermediates=True)
+        z_kd, mids_kd = m(images.cuda(), pts.cuda(), return_intermediates=("camera_feat", "lidar_feat", "logits"))
+    assert set(mids_all) == {"camera_feat", "lidar_feat", "pre_fusion", "post_fusion", "logits"} and mids_all["pre_fusion"].numel() > 0
+    assert set(mids_kd) == {"camera_feat", "lidar_feat", "logits"}
+    assert torch.equal(z_all, z_kd)
+    for k in mids_kd:
+        assert torch.equal(mids_all[k], mids_kd[k]), k
+    with pytest.raises(ValueError):
+        m(images.cuda(), pts.cuda(), return_intermediates=("camera_feat", "no_such_map"))
