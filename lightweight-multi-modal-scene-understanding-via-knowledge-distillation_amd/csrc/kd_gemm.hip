@@ -583,6 +583,11 @@ __device__ __forceinline__ bf16x8 kd_tr_frag(const unsigned short* plane, int ld
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// timing-only probes of dev builds (-DKD_WG_PROBE=bits; results WRONG by construction): 1 one of the six piece products, 2 every chunk
+// loads the slice's FIRST rows (operands stay cache-resident: no HBM latency)
+#ifndef KD_WG_PROBE
+#define KD_WG_PROBE 0
+#endif
 template <int WN, int WK, int WM, int DMODE, int AMODE, bool SPLIT>
 __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs g) {
   constexpr int KS = WM == 1 ? 2 : 1;                           // SPLIT: 16-row MFMA steps per wave per chunk
@@ -653,6 +658,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs 
     }
   };
   auto load_chunk = [&](int64_t mc) {
+    if (KD_WG_PROBE & 2) mc = mbeg;
     if constexpr (DMODE == 3) {
       // the table rows of THIS chunk were fetched one chunk ago (tr_nxt): no dependent load in the steady state
 #pragma unroll
@@ -763,7 +769,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs 
           }
         constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < ((KD_WG_PROBE & 1) ? 1 : 6); ++t)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
