@@ -561,6 +561,7 @@ struct WgradArgs {
   // DMODE 3: D = Y raw (also the BN-backward X); the scatter-max gradient G is rebuilt from trows / tmx / tshare exactly
   // as in pw_gemm_kernel PRO4 (msc / msh / d_act = Y's BatchNorm + activation)
   const float* tmx; const float* tshare; const int* trows;
+  int xcd_order;                      // 1: the output tiles of one row slice go to blocks that share an XCD (see the kernel)
 };
 
 //
@@ -606,11 +607,13 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void pw_wgrad_kernel(WgradArgs 
   const int ntn = (g.N + TN - 1) / TN, ntk = (g.K + TK - 1) / TK;
   // XCD-aware order (speed only, as in pw_gemm_kernel): blocks b, b + 8, b + 16, ... share an L2, so THEY get the ntn * ntk output
   // tiles of one row slice -- its D / A rows then come from HBM once and from that XCD's L2 for the other tiles (round 3; PMC
-  // before: the weight-gradient family moved 1.25x its algorithmic bytes, blockIdx % ntiles having dealt a slice's tiles over all XCDs)
+  // before: the weight-gradient family moved 1.25x its algorithmic bytes, blockIdx % ntiles having dealt a slice's tiles over all XCDs).
+  // Selected per launch (g.xcd_order, launch_wgrad): it is faster for few tiles per slice and slower for many.
   int tile, split;
   {
     const int ntiles = ntn * ntk, nsl = (int)gridDim.x / ntiles, grp = 8 * ntiles, g0 = (int)blockIdx.x / grp, r = (int)blockIdx.x % grp;
-    if ((g0 + 1) * 8 <= nsl) { split = g0 * 8 + (r & 7); tile = r >> 3; }
+    if (!g.xcd_order) { tile = (int)blockIdx.x % ntiles; split = (int)blockIdx.x / ntiles; }
+    else if ((g0 + 1) * 8 <= nsl) { split = g0 * 8 + (r & 7); tile = r >> 3; }
     else { const int rem = nsl - g0 * 8; split = g0 * 8 + r % rem; tile = r / rem; }
   }
   const int n0 = (tile / ntk) * TN, k0 = (tile % ntk) * TK;
@@ -867,6 +870,10 @@ int launch_wgrad(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
   g.rows_per_split = (int)(cps * CH);
   nsplit = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
   const dim3 grid(ntiles * nsplit), blk(256);
+  // measured on the same box (tools/bench_wgrad.py, 256 frames, KD_WGRAD_XCD=0|1): the XCD-aware order wins 1-8 % where a row slice has
+  // three output tiles (64 <-> 384 layers) and LOSES 29-34 % where it has six (128 <-> 768: 462 -> 598 us), so it is chosen by tile count
+  static const int xcd_env = [] { const char* e = getenv("KD_WGRAD_XCD"); return e ? atoi(e) : -1; }();
+  g.xcd_order = xcd_env >= 0 ? xcd_env : (ntiles > 1 && ntiles <= 3);
   if (g.d_mode == 3) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 3, 1, SPLIT>), grid, blk, 0, st, g);
   else if (g.d_mode == 2 && g.a_mode == 2) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 2, SPLIT>), grid, blk, 0, st, g);
   else if (g.d_mode == 2 && g.a_mode == 1) hipLaunchKernelGGL((pw_wgrad_kernel<WN, WK, WM, 2, 1, SPLIT>), grid, blk, 0, st, g);
