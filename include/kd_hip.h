@@ -82,6 +82,10 @@ int kd_transpose(const float* in, float* out, int R, int C, void* stream);
 /* the same for n weights in one launch: table = device int64 [n][5] {in pointer, out pointer, R, C, first 256-element block of
  * this matrix}, first blocks ascending from 0, nblocks = sum of ceil(R*C/256) */
 int kd_transpose_batch(const int64_t* table, int n, int nblocks, void* stream);
+/* up to four small device-to-device float copies in one launch (unused segments: n = 0): packed parameter gradients -> their
+ * slots in a flat gradient buffer */
+int kd_copy_segments(const float* s0, float* d0, int64_t n0, const float* s1, float* d1, int64_t n1, const float* s2, float* d2,
+                     int64_t n2, const float* s3, float* d3, int64_t n3, void* stream);
 
 /* ---- stem 3x3/s2 conv (camera_encoder.py:63-67), NCHW image in, NHWC raw out, Cout == 32 ---- */
 int64_t kd_stem_stat_rows(int64_t npix_out);
@@ -344,6 +348,13 @@ int kd_mse_fwd_bwd(const float* a, const float* b, int64_t n, float gcoef, const
 /* value of the KD objective from its parts: total = ce_kl[0] + ckl * ce_kl[1] + beta * (mse_c[0] + mse_l[0]) (either MSE may be
  * NULL = 0), every operation rounded to fp32 in that order */
 int kd_kd_total(const float* ce_kl, const float* mse_c, const float* mse_l, float ckl, float beta, float* total, void* stream);
+/* the same objective with fewer launches: kd_mse_partial leaves the per-block sums of (a-b)^2 in a slab of kd_mse_slab_blocks(n)
+ * floats (and writes da = gcoef * (a-b) when da != NULL); kd_kd_objective_final reduces two such slabs to out[0], out[1] = the two
+ * feature MSEs and out[2] = the total (rounding order of kd_kd_total) */
+int64_t kd_mse_slab_blocks(int64_t n);
+int kd_mse_partial(const float* a, const float* b, int64_t n, float gcoef, float* da, float* slab, void* stream);
+int kd_kd_objective_final(const float* ce_kl, const float* slab_c, int64_t n_c, const float* slab_l, int64_t n_l, float ckl, float beta,
+                          float* out, void* stream);
 int kd_argmax_confusion(const float* logits, const int64_t* target, int ignore_index, uint64_t* conf,
                         int64_t* pred, int B, int NC, int HW, void* stream);
 int kd_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -141,6 +141,27 @@ __global__ void kd_total_kernel(const float* ce_kl, const float* mse_c, const fl
   }
 }
 
+// the two feature-MSE values from their per-block partial sums (the reduction of mse_final_kernel, same order) and the KD objective's
+// total in one launch: out[0] = mse_c, out[1] = mse_l, out[2] = ce_kl[0] + ckl * ce_kl[1] + beta * (mse_c + mse_l)
+__global__ void kd_objective_final_kernel(const float* ce_kl, const float* slab_c, int nblk_c, double n_c, const float* slab_l, int nblk_l,
+                                          double n_l, float ckl, float beta, float* out) {
+  __shared__ double red[2][256];
+  double sc = 0.0, sl = 0.0;
+  for (int i = threadIdx.x; i < nblk_c; i += 256) sc += (double)slab_c[i];
+  for (int i = threadIdx.x; i < nblk_l; i += 256) sl += (double)slab_l[i];
+  red[0][threadIdx.x] = sc;
+  red[1][threadIdx.x] = sl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tc = 0.0, tl = 0.0;
+    for (int i = 0; i < 256; ++i) { tc += red[0][i]; tl += red[1][i]; }
+    const float mc = (float)(tc / n_c), ml = (float)(tl / n_l);
+    out[0] = mc;
+    out[1] = ml;
+    out[2] = __fadd_rn(__fadd_rn(ce_kl[0], __fmul_rn(ckl, ce_kl[1])), __fmul_rn(beta, __fadd_rn(mc, ml)));
+  }
+}
+
 __global__ void mse_final_kernel(const float* slab, int nblk, double n, float* loss) {
   __shared__ double red[256];
   double s = 0.0;
@@ -248,6 +269,25 @@ int kd_kd_total(const float* ce_kl, const float* mse_c, const float* mse_l, floa
   KD_REQUIRE(ce_kl && total, KD_ERR_ARG, "kd_kd_total: bad args");
   hipLaunchKernelGGL(kd_total_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ce_kl, mse_c, mse_l, ckl, beta, total);
   return kd_check_launch("kd_kd_total");
+}
+
+// kd_mse_fwd_bwd without its one-block final reduction: the per-block sums of (a-b)^2 go to `slab` (kd_mse_slab_blocks(n) floats) for
+// kd_kd_objective_final, da = gcoef * (a-b) as in kd_mse_fwd_bwd (skipped when NULL).
+int64_t kd_mse_slab_blocks(int64_t n) { int64_t g = (n / 4 + 255) / 256; return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
+int kd_mse_partial(const float* a, const float* b, int64_t n, float gcoef, float* da, float* slab, void* stream) {
+  KD_REQUIRE(a && b && slab && n > 0 && n % 4 == 0, KD_ERR_ARG, "kd_mse_partial: bad args (n must be a multiple of 4)");
+  hipLaunchKernelGGL(mse_kernel, dim3((unsigned)kd_mse_slab_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n / 4, gcoef, (const float*)nullptr, da, slab);
+  return kd_check_launch("kd_mse_partial");
+}
+
+// out[0] = mean((a_c-b_c)^2), out[1] = mean((a_l-b_l)^2) from the slabs of two kd_mse_partial calls over n_c / n_l elements, and
+// out[2] = ce_kl[0] + ckl * ce_kl[1] + beta * (out[0] + out[1]) (the rounding order of kd_kd_total): three tiny launches in one.
+int kd_kd_objective_final(const float* ce_kl, const float* slab_c, int64_t n_c, const float* slab_l, int64_t n_l, float ckl, float beta,
+                          float* out, void* stream) {
+  KD_REQUIRE(ce_kl && slab_c && slab_l && out && n_c > 0 && n_l > 0, KD_ERR_ARG, "kd_kd_objective_final: bad args");
+  hipLaunchKernelGGL(kd_objective_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ce_kl, slab_c, (int)kd_mse_slab_blocks(n_c), (double)n_c,
+                     slab_l, (int)kd_mse_slab_blocks(n_l), (double)n_l, ckl, beta, out);
+  return kd_check_launch("kd_kd_objective_final");
 }
 
 // conf[NC*NC] (uint64, ACCUMULATED into) and/or pred[B*HW] (int64 argmax over the class dim).

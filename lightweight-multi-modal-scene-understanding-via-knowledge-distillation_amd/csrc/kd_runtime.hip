@@ -92,7 +92,32 @@ int kd_slab_reduce_launch(const float* slab, int nsplit, int64_t n, float* out, 
   return kd_check_launch("kd_slab_reduce");
 }
 
+namespace {
+struct CopySegs { const float* s[4]; float* d[4]; long long n[4]; long long first[5]; };   // first[i]: first 256-element block of segment i
+__global__ __launch_bounds__(256) void copy_segments_kernel(CopySegs c) {
+  int k = 0;
+  while (k < 3 && (long long)blockIdx.x >= c.first[k + 1]) ++k;
+  const long long i = ((long long)blockIdx.x - c.first[k]) * 256 + threadIdx.x;
+  if (i < c.n[k]) c.d[k][i] = c.s[k][i];
+}
+}  // namespace
+
 extern "C" {
+// Up to four small device-to-device copies in ONE launch (packed parameter gradients -> their slots in the flat gradient buffer:
+// a kernel that produces several parameters' gradients in one workspace hands them over without a copy launch per parameter).
+// Unused segments: n = 0.
+int kd_copy_segments(const float* s0, float* d0, int64_t n0, const float* s1, float* d1, int64_t n1, const float* s2, float* d2,
+                     int64_t n2, const float* s3, float* d3, int64_t n3, void* stream) {
+  CopySegs c{{s0, s1, s2, s3}, {d0, d1, d2, d3}, {n0, n1, n2, n3}, {0, 0, 0, 0, 0}};
+  for (int k = 0; k < 4; ++k) {
+    KD_REQUIRE(c.n[k] >= 0 && (c.n[k] == 0 || (c.s[k] && c.d[k])), KD_ERR_ARG, "kd_copy_segments: segment %d", k);
+    c.first[k + 1] = c.first[k] + (c.n[k] + 255) / 256;
+  }
+  KD_REQUIRE(c.first[4] > 0, KD_ERR_ARG, "kd_copy_segments: nothing to copy");
+  hipLaunchKernelGGL(copy_segments_kernel, dim3((unsigned)c.first[4]), dim3(256), 0, (hipStream_t)stream, c);
+  return kd_check_launch("kd_copy_segments");
+}
+
 int kd_version(void) { return 100; }
 const char* kd_last_error_string(void) { return g_err; }
 const char* kd_arch(void) { return "gfx950"; }

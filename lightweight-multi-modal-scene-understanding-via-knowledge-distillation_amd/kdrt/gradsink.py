@@ -51,13 +51,22 @@ class GradSink:
 _addends: Dict[int, torch.Tensor] = {}
 
 
-def deposit(mat: torch.Tensor, grad: torch.Tensor):
+def deposit(mat: torch.Tensor, grad: torch.Tensor, folded_residual: Optional[torch.Tensor] = None):
+    """`folded_residual`: a gradient that is already part of `grad` and that the collecting residual block would otherwise add
+    for its own skip connection (FPNFn folds d(stage-5 output) into its stage-4 deposit); the collector compares it with the
+    gradient it actually received and corrects the sum if they differ (a third consumer of that output)."""
     if mat.shape != grad.shape or not grad.is_contiguous():
         raise RuntimeError("gradsink.deposit: the addend must be a contiguous tensor shaped like the feature matrix")
-    _addends[mat.data_ptr()] = grad
+    _addends[mat.data_ptr()] = (grad, folded_residual)
 
 
 def collect(mat: torch.Tensor) -> Optional[torch.Tensor]:
+    e = _addends.pop(mat.data_ptr(), None) if _addends else None
+    return None if e is None else e[0]
+
+
+def collect_flagged(mat: torch.Tensor):
+    """-> (gradient, folded residual gradient or None) or None"""
     return _addends.pop(mat.data_ptr(), None) if _addends else None
 
 
@@ -95,6 +104,28 @@ def finish(p: torch.Tensor, buf: torch.Tensor, direct: bool):
         active.done(p)
         return None
     return buf
+
+
+def deliver_many(pairs):
+    """deliver() for up to four (parameter, packed gradient) pairs with ONE copy launch when all of them go to the sink;
+    returns the list deliver() would have returned for each pair."""
+    if active is not None and 1 < len(pairs) <= 4:
+        bufs = [active.buffer(p) for p, _ in pairs]
+        if all(b is not None for b in bufs):
+            from .lib import lib
+            a = []
+            for b, (_, v) in zip(bufs, pairs):
+                v = v.reshape(-1)
+                if not (v.is_contiguous() and b.is_contiguous() and v.numel() == b.numel()):
+                    break
+                a += [ops.P(v), ops.P(b), v.numel()]
+            else:
+                a += [None, None, 0] * (4 - len(pairs))
+                lib.call("kd_copy_segments", *a, ops.stream())
+                for p, _ in pairs:
+                    active.done(p)
+                return [None] * len(pairs)
+    return [deliver(p, v) for p, v in pairs]
 
 
 def deliver(p: torch.Tensor, value: torch.Tensor):

@@ -55,7 +55,11 @@ class KDStep:
         if self.fused_objective:
             return kd_objective_backward(*a)
         total, parts = kd_objective(*a)
+        gradsink.drop_pending()
         total.backward()
+        if gradsink.pending():
+            gradsink.drop_pending()
+            raise RuntimeError("a deposited feature gradient was not collected (kdrt.gradsink): set KD_GRAD_ROUTING=0")
         return total.detach(), parts
 
     def __call__(self, images, points, labels):

@@ -148,20 +148,24 @@ def kd_objective_backward(student_logits, student_mids: Dict[str, torch.Tensor],
              1.0, None, P(vals), P(dzs), B, NC, H * W, P(ws), nbytes, stream())
     roots, grads = [zs], [dzs]
     gradsink.drop_pending()
-    for slot, key in ((4, "camera_feat"), (5, "lidar_feat")):
+    slabs, counts = [], []
+    for key in ("camera_feat", "lidar_feat"):
         a, b = student_mids[key], teacher_mids[key]
         am, _ = ops.nhwc_view(a.detach())
         bm, _ = ops.nhwc_view(b.detach())
         n = am.numel()
         want = beta != 0.0 and a.requires_grad
         da = torch.empty_like(am) if want else None
-        nbytes = lib.kd_mse_ws_bytes(n)
-        ws = ops.workspace(nbytes, dev)
+        slab = torch.empty(lib.kd_mse_slab_blocks(n), device=dev, dtype=torch.float32)
         gcoef = float(np.float32(2.0 / n) * np.float32(beta))      # the product autograd's fp32 chain rule forms
-        lib.call("kd_mse_fwd_bwd", P(am), P(bm), n, gcoef, None, P(vals[slot:]), P(da), P(ws), nbytes, stream())
+        lib.call("kd_mse_partial", P(am), P(bm), n, gcoef, P(da), P(slab), stream())
+        slabs.append(slab)
+        counts.append(n)
         if want:
             gradsink.deposit(am, da)
-    lib.call("kd_kd_total", P(vals), P(vals[4:]), P(vals[5:]), float(alpha * T * T), float(beta), P(vals[6:]), stream())
+    # the two MSE values and the total in one launch (vals[4], vals[5], vals[6])
+    lib.call("kd_kd_objective_final", P(vals), P(slabs[0]), counts[0], P(slabs[1]), counts[1], float(alpha * T * T), float(beta), P(vals[4:]),
+             stream())
     torch.autograd.backward(roots, grads)
     if gradsink.pending():
         gradsink.drop_pending()

@@ -430,7 +430,7 @@ def unit_backward(rec: _Rec, g, need_input_grad: bool = True, addend: Optional[t
         if moments:
             dwb[: C * 4].view(C, 4).addcmul_(al.view(C, 1), t.t())
             dwb[C * 4:].addcmul_(al, dbeta)                      # sum_p G0 == dbeta of this BatchNorm
-        grads = [gradsink.deliver(rec.w, dwb[: C * 4]), gradsink.deliver(rec.b, dwb[C * 4:])]
+        grads = gradsink.deliver_many([(rec.w, dwb[: C * 4]), (rec.b, dwb[C * 4:])])
     elif kind == "ct":
         inp = rec.inp
         B, H, W = inp.geom
@@ -509,8 +509,19 @@ class ChainFn(torch.autograd.Function):
     def backward(ctx, dout):
         dm, _ = ops.nhwc_view(dout)
         need = ctx.needs_input_grad[0] and ctx.recs[0].spec.kind != "stem"
-        grads, g_in = chain_backward(ctx.recs, ("D", dm), need_input_grad=need,
-                                     first_addend=dm if ctx.residual else None)
+        first_addend = dm if ctx.residual else None
+        dep = gradsink.collect_flagged(ctx.recs[0].inp.raw) if (need and ctx.recs[0].inp.bnc is None) else None
+        if dep is not None:            # a later consumer of this chain's input left its gradient for the first data-gradient kernel
+            g2, folded = dep
+            if not ctx.residual:
+                first_addend = g2 if folded is None else g2 - folded        # (a fold meant for a residual block that is not one)
+            elif folded is None:
+                first_addend = dm + g2                                      # two addends, one slot: one elementwise pass
+            elif folded.data_ptr() == dm.data_ptr():
+                first_addend = g2                                           # g2 already contains this block's skip-connection term dm
+            else:
+                first_addend = g2 + (dm - folded)                           # the output had a third consumer: correct the folded term
+        grads, g_in = chain_backward(ctx.recs, ("D", dm), need_input_grad=need, first_addend=first_addend)
         dx = None
         if need:
             dx = ops.nchw_from_matrix(g_in, ctx.recs[0].inp.geom)
@@ -562,6 +573,13 @@ class PairChainFn(torch.autograd.Function):
 
 
 _CHAIN_PAIRS = os.environ.get("KD_CHAIN_PAIRS", "1") != "0"
+_GRAD_ROUTING = os.environ.get("KD_GRAD_ROUTING", "1") != "0"     # 0: two-consumer feature gradients summed by autograd
+
+
+def grad_routing(training: bool) -> bool:
+    """May the encoder mark its two-consumer maps for gradient deposits (FPNFn.backward -> ChainFn.backward)?  Only inside a
+    training step that checks `gradsink.pending()` after backward (a gradient sink is installed: KDStep, Trainer)."""
+    return bool(_GRAD_ROUTING and training and torch.is_grad_enabled() and gradsink.active is not None)
 
 
 def chain_pair_ok(units_a: Sequence[UnitSpec], units_b: Sequence[UnitSpec], training: bool, out_w: int) -> bool:
@@ -620,6 +638,18 @@ class FPNFn(torch.autograd.Function):
             post_recs.append(rec)
         out = ops.materialize(cur)
         ctx.lat_ops, ctx.lat_recs, ctx.post_recs, ctx.geom, ctx.n_stage = lat_ops, lat_recs, post_recs, (B, Ho, Wo), n_stage
+        # Gradient routing for maps with a second consumer (marks set by TwinLiteEncoder.forward, training only): a map marked
+        # `_kd_deposit` is ALSO the input of the next encoder stage, whose backward runs after this one -- its gradient from here
+        # is deposited for that stage's data-gradient kernel instead of being summed by an autograd accumulation pass; a map
+        # marked `_kd_residual_of = other` is the output of a residual block over `other`, so its gradient is folded into
+        # `other`'s deposit (the block's skip-connection term) by the lateral's own data-gradient kernel.
+        ctx.deposit = [bool(getattr(f, "_kd_deposit", False)) and _GRAD_ROUTING and training for f in feats]
+        ctx.res_src = [None] * n_stage                        # res_src[j] = i: feats[i] is a residual block's output over feats[j]
+        for i, f in enumerate(feats):
+            tgt = getattr(f, "_kd_residual_of", None)
+            for j, h in enumerate(feats):
+                if tgt is not None and h is tgt and ctx.deposit[j] and f.shape == h.shape:
+                    ctx.res_src[j] = i
         return ops.nchw_from_matrix(out, cur.geom)
 
     @staticmethod
@@ -628,7 +658,11 @@ class FPNFn(torch.autograd.Function):
         post_grads, dfused = chain_backward(ctx.post_recs, ("D", dm), need_input_grad=True)
         B, Ho, Wo = ctx.geom
         feat_grads, lat_grads = [], []
-        for i, (op, rec) in enumerate(zip(ctx.lat_ops, ctx.lat_recs)):
+        n = ctx.n_stage
+        order = sorted(range(n), key=lambda k: 0 if k in ctx.res_src else 1)       # residual sources first: their gradient is an addend
+        gmat, pgs = [None] * n, [None] * n
+        for i in order:
+            op, rec = ctx.lat_ops[i], ctx.lat_recs[i]
             _, Hi, Wi = op.geom
             C = op.C
             rows = lib.kd_rowwise_stat_rows(op.M, C)
@@ -637,9 +671,15 @@ class FPNFn(torch.autograd.Function):
             lib.call("kd_bilinear_bwd", P(dfused), P(op.raw), P(op.sc), P(op.sh), op.act, P(op.bnc.mean),
                      P(op.bnc.invstd), P(gin), P(partial), B, Hi, Wi, Ho, Wo, C, stream())
             need = ctx.needs_input_grad[5 + i]
-            pg, gx = unit_backward(rec, ("G", gin, partial, rows), need_input_grad=need)
-            lat_grads += pg
-            feat_grads.append(ops.nchw_from_matrix(gx, rec.inp.geom) if need else None)
+            src = ctx.res_src[i]
+            fold = need and src is not None and gmat[src] is not None
+            pgs[i], gmat[i] = unit_backward(rec, ("G", gin, partial, rows), need_input_grad=need, addend=gmat[src] if fold else None)
+            if need and ctx.deposit[i]:
+                gradsink.deposit(rec.inp.raw, gmat[i], folded_residual=gmat[src] if fold else None)
+        for i in range(n):
+            lat_grads += pgs[i]
+            keep = ctx.needs_input_grad[5 + i] and not ctx.deposit[i]
+            feat_grads.append(ops.nchw_from_matrix(gmat[i], ctx.lat_recs[i].inp.geom) if keep else None)
         return (None, None, None, None, None, *feat_grads, *lat_grads, *post_grads)
 
 
@@ -795,9 +835,7 @@ class WeightedFuseFn(torch.autograd.Function):
         ws = ops.workspace(nbytes, dev)
         lib.call("kd_weighted_fuse_bwd", P(dm), P(cat), P(comb.scale), P(comb.shift), P(ctx.hraw), P(ctx.w2), P(ctx.wts),
                  P(dcat), P(gh), P(dpar), M, C, P(ws), nbytes, stream())
-        dw2 = gradsink.deliver(ctx.w2, dpar[: 2 * C])
-        db1 = gradsink.deliver(ctx.b1, dpar[2 * C: 3 * C])
-        db2 = gradsink.deliver(ctx.b2, dpar[3 * C: 3 * C + 2])
+        dw2, db1, db2 = gradsink.deliver_many([(ctx.w2, dpar[: 2 * C]), (ctx.b1, dpar[2 * C: 3 * C]), (ctx.b2, dpar[3 * C: 3 * C + 2])])
         dw1, w1_dir = gradsink.out_for(ctx.w1)
         ops.pw_wgrad(gh, cat, dw1, M=M, N=C, K=2 * C, d_mode=0, a_mode=1, a_act=ACT_RELU, asc=comb.scale, ash=comb.shift)
         w1t = ops.transpose(ctx.w1.view(C, 2 * C), owner=ctx.w1)
@@ -887,7 +925,8 @@ class SameHeadFn(torch.autograd.Function):
                  P(wc), P(gx), P(partial), P(dwb), M, H * W, Cin, NC, P(ws), nbytes, stream())
         grads, g_in = chain_backward(ctx.recs, ("G", gx, partial, rows), need_input_grad=ctx.needs_input_grad[0])
         dx = ops.nchw_from_matrix(g_in, ctx.recs[0].inp.geom) if ctx.needs_input_grad[0] else None
-        return (dx, None, None, gradsink.deliver(wc, dwb[: NC * Cin]), gradsink.deliver(ctx.bc, dwb[NC * Cin: NC * Cin + NC]),
+        dwc, dbc = gradsink.deliver_many([(wc, dwb[: NC * Cin]), (ctx.bc, dwb[NC * Cin: NC * Cin + NC])])
+        return (dx, None, None, dwc, dbc,
                 *grads)
 
 
@@ -934,7 +973,8 @@ class X4HeadFn(torch.autograd.Function):
                  P(wc), P(gx), P(partial), P(dwb), B, H, W, Cin, NC, P(ws), nbytes, stream())
         grads, g_in = chain_backward(ctx.recs, ("G", gx, partial, rows), need_input_grad=ctx.needs_input_grad[0])
         dx = ops.nchw_from_matrix(g_in, ctx.recs[0].inp.geom) if ctx.needs_input_grad[0] else None
-        return (dx, None, None, gradsink.deliver(wc, dwb[:nw].view_as(wc)), gradsink.deliver(ctx.bc, dwb[nw: nw + NC]),
+        dwc, dbc = gradsink.deliver_many([(wc, dwb[:nw]), (ctx.bc, dwb[nw: nw + NC])])
+        return (dx, None, None, dwc, dbc,
                 *grads)
 
 

@@ -88,6 +88,14 @@ class TwinLiteEncoder(nn.Module):
             x3 = self.stage3(x2)
         x4 = self.stage4(x3)
         x5 = self.stage5(x4)
+        if self.return_multiscale and U.grad_routing(self.training):
+            # x3 / x4 feed the next stage AND the FPN: let the FPN's backward (which runs first) deposit their gradients for the
+            # next stage's data-gradient kernel instead of an autograd accumulation pass over each map (kdrt/units.py: FPNFn)
+            if not self.stage4.use_residual:
+                x3._kd_deposit = True
+            x4._kd_deposit = True
+            if self.stage5.use_residual:
+                x5._kd_residual_of = x4
         if self.return_multiscale:
             maps = {"stage2": x2, "stage3": x3, "stage4": x4, "stage5": x5}
             return {k: v for k, v in maps.items() if v is not None}

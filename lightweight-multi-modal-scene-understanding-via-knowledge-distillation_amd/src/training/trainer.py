@@ -126,6 +126,9 @@ class Trainer:
         logits = self.model(imgs, pts)
         loss = self.criterion(logits, seg)
         loss.backward()
+        if gradsink.pending():           # a feature-map gradient deposited for a later kernel that never ran: a missing gradient term
+            gradsink.drop_pending()
+            raise RuntimeError("a deposited feature gradient was not collected (kdrt.gradsink): unsupported model structure; set KD_GRAD_ROUTING=0")
         self.optimizer.grad_scale = self.reducer.finish() if self.reducer is not None else 1.0
         self.optimizer.step()
         return loss.detach(), logits.detach()

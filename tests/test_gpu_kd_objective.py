@@ -128,3 +128,28 @@ def test_return_intermediates_by_name():
         assert torch.equal(mids_all[k], mids_kd[k]), k
     with pytest.raises(ValueError):
         m(images.cuda(), pts.cuda(), return_intermediates=("camera_feat", "no_such_map"))
+
+
+@pytest.mark.parametrize("student_fusion", ("weighted", "concat"))
+def test_feature_gradient_routing_matches_autograd_accumulation(student_fusion, monkeypatch):
+    """Stage-3 / stage-4 maps feed the next encoder stage AND the FPN.  With routing, the FPN's backward deposits their gradients
+    for the next stage's data-gradient kernel (and folds d(stage-5 output) into the stage-4 deposit: stage 5 is a residual block
+    over stage 4's map) instead of autograd summing two gradient tensors per map.  Same losses; gradients equal up to the
+    association of one three-term sum (a + d5) + f4  vs  a + (f4 + d5)."""
+    from kdrt import gradsink, units
+    shape = (2, 64, 700, 16)
+    res = {}
+    for routing in (False, True):
+        monkeypatch.setattr(units, "_GRAD_ROUTING", routing)
+        seen = []
+        real = gradsink.deposit
+        monkeypatch.setattr(gradsink, "deposit", lambda *a, **k: (seen.append(k.get("folded_residual") is not None), real(*a, **k))[1])
+        res[routing] = _one_step(student_fusion, True, 1.0, shape)
+        # the two feature-MSE deposits always; with routing also the stage-3 and the stage-4 map (the latter with the fold)
+        assert len(seen) == (4 if routing else 2) and sum(seen) == (1 if routing else 0), seen
+        monkeypatch.setattr(gradsink, "deposit", real)
+    (p0, g0), (p1, g1) = res[False], res[True]
+    for k in p0:
+        assert torch.equal(p0[k].view(torch.int32), p1[k].view(torch.int32)), k
+    assert (g0 - g1).abs().max().item() <= 2e-6 * g0.abs().max().item(), (g0 - g1).abs().max().item()
+    assert gradsink.pending() == 0

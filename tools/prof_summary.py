@@ -29,6 +29,9 @@ with open(out, "w", newline="") as f:
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
     for n, v in sorted(per.items(), key=lambda kv: -kv[1][1]):
         w.writerow([n, v[0], v[1], v[1] / v[0], 100.0 * v[1] / tot])
+idx = [i for i, r in enumerate(rows) if "adamw_tick_kernel" in r["Kernel_Name"]]
+print("launches per step (cut at adamw_tick_kernel):", [b - a for a, b in zip(idx[:-1], idx[1:])],
+      "-- bench.py's two HIP-event-profiled roofline steps and their first-use allocations are among the kept ones")
 print(f"{len(ticks)} steps in the trace, the last {keep} kept (warm-up dropped): {len(win)} launches = {len(win)/steps:.1f} launches/step, "
       f"wall {(hi - lo)/1e6/steps:.2f} ms/step, kernel time {tot/1e6/steps:.2f} ms/step")
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("kd_stream::", "").replace("void ", "")
