@@ -94,9 +94,18 @@ class GraphedKDStep:
     The capture then runs in "thread_local" error mode (the process group's watchdog thread polls events of earlier
     collectives from another thread, which the default "global" mode would treat as a capture violation).
 
-    Restrictions: fixed batch shape; `optimizer.sync_lr()` happens automatically before each replay."""
+    Restrictions: fixed batch shape; `optimizer.sync_lr()` happens automatically before each replay; more than one rank is
+    an explicit opt-in (see __init__)."""
 
-    def __init__(self, step: KDStep, images, points, labels, warmup: int = 3):
+    def __init__(self, step: KDStep, images, points, labels, warmup: int = 3, allow_multi_rank: bool = False):
+        # Captured collectives have only ever executed in a world of ONE rank here (tests/test_gpu_rccl_world1.py: a real RCCL
+        # communicator, forced buckets); a multi-rank capture or replay problem would show as a hang in user training, so a
+        # world of more than one rank is refused unless the caller opts in (`allow_multi_rank=True` / KD_GRAPH_MULTI_RANK=1)
+        # -- to be lifted once a multi-GPU run has executed the captured path.
+        world = step.reducer.world if step.reducer is not None else 1
+        if world > 1 and not (allow_multi_rank or os.environ.get("KD_GRAPH_MULTI_RANK") == "1"):
+            raise RuntimeError(f"GraphedKDStep: capturing the gradient all-reduces of a {world}-rank job has not run on hardware "
+                               "yet; pass allow_multi_rank=True (or KD_GRAPH_MULTI_RANK=1) to try it, or use the eager KDStep")
         self.step = step
         self.images, self.points, self.labels = images.clone(), points.clone(), labels.clone()
         side = torch.cuda.Stream()

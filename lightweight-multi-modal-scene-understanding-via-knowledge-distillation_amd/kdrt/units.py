@@ -41,9 +41,17 @@ class _Rec:
 
 
 # KD_EVAL_COEFF_CACHE=0 recomputes the eval coefficients on every use (triage of a suspected stale cache).  Contract for code
-# that writes parameters or BatchNorm buffers behind torch's back -- `p.data.copy_()` bumps `_version` and is seen, but a raw
-# pointer write, `p.data = ...` re-pointing inside a kernel-side update, or a collective on `.data` is not: call
-# `kdrt.ops.bump_global_epoch()` afterwards (FusedAdamW, kd_bn_finalize_train, GraphedKDStep and the ddp broadcast do).
+# that writes parameters or BatchNorm buffers behind torch's back -- an in-place op on the tensor itself under no_grad
+# (`p.copy_()`, what load_state_dict does) bumps `_version` and is seen; ANY write through `p.data` (`p.data.copy_()`,
+# `p.data.mul_()`: on this torch the version counter of `p` stays where it was), a raw pointer write, a kernel-side update or
+# a collective on `.data` is not: call `kdrt.ops.bump_global_epoch()` afterwards (FusedAdamW, kd_bn_finalize_train,
+# GraphedKDStep and the ddp broadcast do; a user-side EMA over `.data` must too).  load_state_dict also bumps it (post-hook
+# installed by CompleteSegmentationModel / the encoders) so that a state dict whose tensors alias the old ones is never stale.
+def stale_cache_guard(module):
+    """load_state_dict post-hook of the model classes: whatever the loaded tensors alias, the content-keyed caches start over."""
+    module.register_load_state_dict_post_hook(lambda m, incompatible: ops.bump_global_epoch())
+
+
 _EVAL_COEFF_CACHE = os.environ.get("KD_EVAL_COEFF_CACHE", "1") != "0"
 _DW_BWD_ADD = os.environ.get("KD_DW_BWD_ADD", "1") != "0"        # 0: residual gradient of a depthwise-first block added by a separate pass
 

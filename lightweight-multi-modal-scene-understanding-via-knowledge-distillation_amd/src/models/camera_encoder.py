@@ -54,6 +54,7 @@ class InvertedResidual(nn.Module):
 class TwinLiteEncoder(nn.Module):
     def __init__(self, in_channels=3, base_channels=32, return_multiscale=False):
         super().__init__()
+        U.stale_cache_guard(self)
         self.return_multiscale = return_multiscale
         stem = []
         _conv_bn(stem, in_channels, base_channels, 3, 2, 1, True)
@@ -67,11 +68,16 @@ class TwinLiteEncoder(nn.Module):
         self.feature_channels = {"stage2": b * 2, "stage3": b * 2, "stage4": b * 4, "stage5": b * 4}
         self.out_channels = b * 4
 
-    def forward(self, x):
+    _kd_accepts_skip = True
+
+    def forward(self, x, _skip_stages=()):
+        """`_skip_stages` (not in the reference's signature; keyword-only use by CompleteSegmentationModel): multiscale maps the
+        CALLER promises not to read -- they are left out of the returned dict.  Without it the key set is the reference's,
+        {stage2, stage3, stage4, stage5}, in train() and eval() alike."""
         stem = U.UnitSpec("stem", self.stem[0], self.stem[1], ACT_RELU6)
         # Training: a block that feeds ONLY the residual block after it hands its output over un-materialised (PairChainFn):
-        # the stem -> stage1 always; stage2 -> stage3 unless somebody reads stage2's map (the owning model says which
-        # multiscale maps it uses through `unused_stages`; by default every map is produced, as in the reference).
+        # the stem -> stage1 always; stage2 -> stage3 unless somebody reads stage2's map (the owning model says per call which
+        # multiscale maps it will not read; by default every map is produced, as in the reference).
         w0 = (x.shape[-1] - 1) // 2 + 1
         u1 = self.stage1._units()
         if self.stage1.use_residual and U.chain_pair_ok([stem], u1, self.training, w0):
@@ -80,7 +86,7 @@ class TwinLiteEncoder(nn.Module):
             x1 = self.stage1(U.run_chain(x, [stem], False, self.training))
         x2 = None
         u2, u3 = self.stage2._units(), self.stage3._units()
-        skip2 = (not self.return_multiscale) or "stage2" in getattr(self, "unused_stages", ())
+        skip2 = (not self.return_multiscale) or "stage2" in _skip_stages
         if skip2 and self.stage3.use_residual and not self.stage2.use_residual and U.chain_pair_ok(u2, u3, self.training, 0):
             x3 = U.run_chain_pair(x1, u2, u3, self.training)
         else:

@@ -156,6 +156,7 @@ class CompleteSegmentationModel(nn.Module):
                  camera_fpn_stages: Optional[List[str]] = None, camera_fpn_channels: int = 128,
                  output_mode: str = "same"):
         super().__init__()
+        U.stale_cache_guard(self)
         self.camera_encoder = camera_encoder
         self.lidar_encoder = lidar_encoder
         self.fusion_type = fusion_type
@@ -166,7 +167,9 @@ class CompleteSegmentationModel(nn.Module):
             self.camera_fpn = CameraFPNLite(in_channels_by_stage=camera_encoder.get_feature_info(),
                                             target_channels=camera_fpn_channels, stages_to_use=camera_fpn_stages)
             # tell the encoder which multiscale maps nobody reads (it may then skip materialising them in training)
-            camera_encoder.unused_stages = tuple(s for s in camera_encoder.get_feature_info() if s not in self.camera_fpn.stages_to_use)
+            # maps of the encoder nobody downstream reads: passed PER CALL (`_skip_stages`), never set on the encoder -- called
+            # directly, the encoder returns the reference's full key set in train() and eval() alike (camera_encoder.py:105-115)
+            self._cam_skip = tuple(s for s in camera_encoder.get_feature_info() if s not in self.camera_fpn.stages_to_use)
             cam_ch = camera_fpn_channels
         else:
             cam_ch = getattr(camera_encoder, "out_channels", 128)
@@ -199,7 +202,10 @@ class CompleteSegmentationModel(nn.Module):
             unknown = names - {"camera_feat", "lidar_feat", "pre_fusion", "post_fusion", "logits"}
             if unknown:
                 raise ValueError(f"unknown intermediates {sorted(unknown)}")
-        cam_raw = self.camera_encoder(images)
+        if self.use_multiscale and getattr(self.camera_encoder, "_kd_accepts_skip", False):
+            cam_raw = self.camera_encoder(images, _skip_stages=self._cam_skip)
+        else:
+            cam_raw = self.camera_encoder(images)
         cam_feat = self.camera_fpn(cam_raw) if isinstance(cam_raw, dict) else cam_raw
         lidar_feat = _match_size(cam_feat, self.lidar_encoder(points))       # fusion_module.py:238-240
         if isinstance(self.fusion, ConcatenationFusion):

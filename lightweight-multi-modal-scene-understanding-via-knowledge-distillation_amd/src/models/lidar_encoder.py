@@ -22,6 +22,7 @@ class SpatialLiDAREncoder(nn.Module):
     def __init__(self, input_dim: int = 4, feature_dim: int = 128, grid_size: Tuple[int, int] = (128, 128),
                  point_cloud_range: List[float] = [-50, -50, -5, 50, 50, 3], use_vectorized: bool = True):
         super().__init__()
+        U.stale_cache_guard(self)
         self.grid_size = grid_size
         self.feature_dim = feature_dim
         self.point_cloud_range = point_cloud_range

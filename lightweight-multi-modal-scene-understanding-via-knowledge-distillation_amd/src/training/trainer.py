@@ -121,6 +121,7 @@ class Trainer:
     # one optimisation step; overridden by KDTrainer
     def _step(self, imgs, pts, seg):
         gradsink.active = self.sink
+        gradsink.drop_pending()          # nothing deposited by an earlier step that failed half-way (a caught OOM) may leak into this one
         self.sink.begin_step()
         self.optimizer.zero_grad()
         logits = self.model(imgs, pts)

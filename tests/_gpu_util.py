@@ -50,14 +50,14 @@ def max_err(a: torch.Tensor, b: torch.Tensor):
     return d, d / max(b.abs().max().item(), 1e-12)
 
 
-def ftol(ref: torch.Tensor, base=1e-4, rel=8e-6) -> float:
-    """Forward tolerance: abs 1e-4 (north_star) for O(1..10) tensors; for the eval-mode fixtures
-    whose randomised running statistics blow activations up to 1e2..1e3, 1e-4 is below fp32
-    resolution of the values themselves, so allow 8e-6 of the tensor's max magnitude.  (Round 3: 5e-6 -> 8e-6.  The worst
-    case is weighted-fusion `pre_fusion` (max 319): the fp32 CPU oracle itself is 1.5e-6 of the maximum from its float64
-    evaluation there, round 2's layer-by-layer GPU path sat at 4.9e-6 -- 98 % of the old limit -- and the one-kernel eval LiDAR
-    encoder, whose own output is as close to float64 as the layered one (4-5e-7), lands at 5.9e-6 through the same
-    ill-conditioned BatchNorm; gpurun_out/r3t/acc.log has both paths side by side.)"""
+def ftol(ref: torch.Tensor, base=1e-4, rel=5e-6) -> float:
+    """Forward tolerance for the eval-mode fixtures with ARBITRARY running statistics (`randomize_state`): they blow
+    activations up to 1e2..1e3, where abs 1e-4 is below fp32 resolution of the values themselves, so allow 5e-6 of the
+    tensor's max magnitude there.  The north-star tolerance as written -- abs 1e-4, no scaling -- is asserted on well-scaled
+    activations by tests/test_gpu_headline.py (eval on calibrated statistics, train mode, the benchmarked frame shape).
+    One comparison needs rel = 8e-6 and passes it explicitly (weighted-fusion `pre_fusion`, max 319: the fp32 CPU oracle is
+    1.5e-6 of the maximum from its own float64 evaluation there, the one-kernel eval LiDAR encoder lands at 5.9e-6 through
+    the same ill-conditioned BatchNorm while its own output is 4-5e-7 from float64)."""
     return max(base, rel * ref.detach().abs().max().item())
 
 
@@ -120,20 +120,34 @@ def fp64_oracle_grads(student_fusion: str, objective: str, seed: int, dtype):
 
 
 def fp64_gpu_grads(student_fusion: str, objective: str, seed: int):
-    from kdrt.losses import kd_objective, seg_loss
-    images, pts, labels = O.make_inputs(FP64_B, FP64_HW, FP64_N, FP64_G, seed, pad_tail=40)
+    """The product's DEFAULT step paths, so that the gradient sink and the feature-gradient routing are in a defined state
+    whatever ran before: "kd" = kdrt.kd.KDStep with its default flags (fused objective, sink installed by the step), "ce" =
+    the sequence of src/training/trainer.py:Trainer._step.  lr = 0: AdamW leaves the parameters alone, the gradients stay in
+    the flat buffer."""
+    from kdrt import gradsink
+    from kdrt.kd import KDStep
+    from kdrt.losses import seg_loss
+    from kdrt.optim import FusedAdamW
+    images, pts, labels = (t.cuda() for t in O.make_inputs(FP64_B, FP64_HW, FP64_N, FP64_G, seed, pad_tail=40))
     cw = torch.tensor([0.4, 3.5]).cuda()
     student = build_product(student_fusion, FP64_G); load_random_state(student, student_fusion, 12); student.train()
-    zs, ms = student(images.cuda(), pts.cuda(), return_intermediates=True)
-    if objective == "kd":
-        teacher = build_product("concat", FP64_G); load_random_state(teacher, "concat", 11); teacher.eval()
-        with torch.no_grad():
-            zt, mt = teacher(images.cuda(), pts.cuda(), return_intermediates=True)
-        total, _ = kd_objective(zs, ms, zt, mt, labels.cuda(), cw, 4.0, 1.0, 1.0, -1)
-    else:
-        total, _ = seg_loss(zs, labels.cuda(), cw)
-    total.backward()
-    return {n: p.grad.detach().double().cpu() for n, p in student.named_parameters()}
+    opt = FusedAdamW(student.parameters(), lr=0.0, weight_decay=0.0)
+    try:
+        if objective == "kd":
+            teacher = build_product("concat", FP64_G); load_random_state(teacher, "concat", 11); teacher.eval()
+            KDStep(student, teacher, opt, cw, T=4.0, alpha=1.0, beta=1.0)(images, pts, labels)
+        else:
+            sink = gradsink.install(opt.flat, None)
+            gradsink.drop_pending()
+            sink.begin_step()
+            opt.zero_grad()
+            total, _ = seg_loss(student(images, pts), labels, cw)
+            total.backward()
+            assert not gradsink.pending()
+        return {n: p.grad.detach().double().cpu() for n, p in student.named_parameters()}
+    finally:
+        gradsink.uninstall()
+        gradsink.drop_pending()
 
 
 def fp64_rel_errors(g64, g):

@@ -50,6 +50,19 @@ def test_two_ranks_equal_two_replicas_with_averaged_gradients(tmp_path):
     assert res[0]["total"] != res[1]["total"]                              # different shards of the batch
 
 
+@pytest.mark.parametrize("k", (2, 4))
+def test_k_ranks_against_reference_replicas(tmp_path, k):
+    """the data-parallel step against k REFERENCE replicas (oracle/make_golden.py section 11)."""
+    _torchrun(os.path.join(HERE, "_ddp_ref_worker.py"), k, {"KD_DDP_OUT": str(tmp_path)})
+    for r in range(k):
+        res = json.load(open(tmp_path / f"ref_rank{r}.json"))
+        assert res["loss_err"] < 1e-4, res
+        assert res["bn_stem_err"] < 1e-5 and res["bn_lidar_err"] < 1e-4, res      # per-replica BatchNorm statistics
+        assert not res["bad_grad_digests"] and not res["bad_param_digests"], res
+        assert res["head_cls_err"] < 2e-3 and res["stem_err"] < 5e-3, res
+        assert res["grad_scale"] == 1.0 / k
+
+
 def test_fusion_ablation_entry_script_under_torchrun_with_ragged_shards(tmp_path):
     """train_with_fusion_ablation.py, 2 ranks, 9 training frames (scenes of 3 frames, 3 train scenes): frames are
     sharded in equal counts, both ranks run the same number of steps, CE training is synchronised (base Trainer),

@@ -28,8 +28,9 @@ def test_eval_forward_vs_oracle_and_golden(fusion):
     ref = oracle_run(st, fusion, images, pts, G, training=False)
     gd = golden(f"model_{fusion}_s0.npz")
     for k in ("camera_feat", "lidar_feat", "pre_fusion", "post_fusion"):
-        assert max_err(mids[k], ref[k])[0] < ftol(ref[k]), k
-        assert max_err(mids[k], torch.from_numpy(gd["eval_" + k]))[0] < ftol(ref[k]), k
+        rel = 8e-6 if fusion == "weighted" and k in ("pre_fusion", "post_fusion") else 5e-6      # see _gpu_util.ftol
+        assert max_err(mids[k], ref[k])[0] < ftol(ref[k], rel=rel), k
+        assert max_err(mids[k], torch.from_numpy(gd["eval_" + k]))[0] < ftol(ref[k], rel=rel), k
     for k, v in ms.items():
         assert max_err(v, torch.from_numpy(gd["eval_" + k]))[0] < ftol(v), k
     assert max_err(logits, ref["logits"])[0] < ftol(ref["logits"])
@@ -75,9 +76,15 @@ def test_train_step_vs_oracle(fusion):
             assert max_err(sd[k], v)[0] < 1e-4 * max(1.0, v.abs().max().item()), k
         if k.endswith("num_batches_tracked"):
             assert int(sd[k]) == int(v) == 1, k
-    conf, _ = confusion(logits, labels.cuda())
-    assert np.array_equal(conf.cpu().numpy(), O.confusion_matrix(ref["logits"], labels).numpy()) or \
-        (ref["logits"][:, 0] - ref["logits"][:, 1]).abs().min() < 4 * LOGIT_TOL
+    # class indices / confusion matrix: bit-exact on every pixel whose oracle margin exceeds the numeric tolerance (the
+    # others are handed to the kernel as ignore_index on both sides, so a close call cannot waive the whole comparison)
+    zr = ref["logits"]
+    safe = (zr[:, 0] - zr[:, 1]).abs() > 4 * LOGIT_TOL
+    assert safe.float().mean() > 0.95
+    lab_safe = torch.where(safe, labels, torch.full_like(labels, -1))
+    conf, pred = confusion(logits, lab_safe.cuda())
+    assert np.array_equal(conf.cpu().numpy(), O.confusion_matrix(zr, lab_safe).numpy())
+    assert torch.equal(pred.cpu()[safe], zr.argmax(1)[safe])
 
 
 def test_lidar_edge_cases_bit_exact_cells():
@@ -217,10 +224,10 @@ def test_gradients_against_fp64_oracle(case):
     step) must be as close to it as the fp32 CPU oracle is (measured: both ~2.5e-6 median, < 1e-5 max) -- a systematic
     error of a few 1e-4 (round 2's statistics-slab row-count bug) is 100x over the line.
 
-    Three scanned seeds per case, at least TWO must pass.  Whether a batch sits on a kink depends on the last bit of every
-    sum before it, so any later change of a summation order (a new reduction layout, another tile shape) can move ONE of the
-    committed batches onto a kink -- a 1e-2-class error in that batch alone, which says nothing about the kernels; a real
-    gradient error fails all three.  A failing seed is reported so the table can be re-scanned."""
+    Three scanned seeds per case and ALL THREE must pass (round 3 let one of three fail; ADVICE r3: a data-dependent kernel
+    bug -- a tail chunk, a tile boundary -- shows in one batch exactly like a ReLU kink would).  Whether a batch sits on a
+    kink depends on the last bit of every sum before it, so a change of a summation order can move a committed batch onto
+    one: the scan (tools/diag_fp64_seeds.py) is re-run on the GPU whenever kernels change and the table re-committed."""
     objective, fusion = case.split("/")
     seeds = _fp64_table()[case]
     assert len(seeds) >= 3, "tests/golden/fp64_clean_seeds.json: three scanned seeds per case"
@@ -233,7 +240,7 @@ def test_gradients_against_fp64_oracle(case):
     bad = [v for v in verdicts if not v[1]]
     for v in bad:
         print(f"{case} seed {v[0]}: GPU median {v[2]:.2e} max {v[3]:.2e} vs CPU fp32 {v[4]:.2e} / {v[5]:.2e} -- re-scan (tools/diag_fp64_seeds.py)")
-    assert len(bad) <= 1, verdicts
+    assert not bad, verdicts
 
 
 def test_fp64_gradient_check_goes_red_on_a_wrong_statistics_row_count(monkeypatch):
