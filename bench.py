@@ -112,9 +112,47 @@ def cpu_baseline(teacher, student, N, HW, grid, teacher_fusion, student_fusion, 
         one(1 + warm + i)
     dt = (time.perf_counter() - t0) / iters
     cut = "" if (warm, iters) == (3, 10) else f" (cut from 3 + 10 to fit {budget_s:.0f} s: first step took {first:.1f} s)"
-    return {"value": round(B / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} timed KD steps of B={B} frames after {warm} warm-up steps{cut}, N={N} points, image {HW}x{HW}, "
-                      f"{teacher_fusion} teacher -> {student_fusion} student ({dt*1e3:.0f} ms/step, torch CPU threads={torch.get_num_threads()})"}
+    res = {"value": round(B / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"{iters} timed KD steps of B={B} frames after {warm} warm-up steps{cut}, N={N} points, image {HW}x{HW}, "
+                     f"{teacher_fusion} teacher -> {student_fusion} student ({dt*1e3:.0f} ms/step, torch CPU threads={torch.get_num_threads()})"}
+    # BASELINE.md section 3 cases (a) and (b), same port, same cores, 3 warm-up + 10 timed iterations each:
+    # (a) configs[0]: camera encoder alone, eval forward of a random 4x3x224x224 batch (test_camera_encoder.py:24-40)
+    cam_st = {k[len("camera_encoder."):]: v for k, v in t_st.items() if k.startswith("camera_encoder.")}
+    x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+
+    def timed(fn, warm=3, iters=10):
+        for _ in range(warm):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        return (time.perf_counter() - t0) / iters
+    with torch.no_grad():
+        ta = timed(lambda: O.twinlite_encoder(x, cam_st, "", False, False))
+    # (b) the reference trainer's own step (trainer.py:86-90): weighted CE, backward, AdamW; B=4, N=5000 (the reference's
+    # default points per frame)
+    im5, pt5, lb5 = synth_batch(B, 5000, HW, grid, 4321, "cpu")
+    s5 = O.clone_state({k: v.detach().cpu().clone() for k, v in student.state_dict().items()}, requires_grad=True)
+    m5 = [torch.zeros_like(s5[k]) for k in keys]
+    v5 = [torch.zeros_like(s5[k]) for k in keys]
+    n5 = [0]
+
+    def ce_step():
+        n5[0] += 1
+        for k in keys:
+            s5[k].grad = None
+        z, _ = O.complete_model(im5, pt5, s5, fusion_type=student_fusion, grid=(grid, grid), training=True)
+        O.weighted_ce(z, lb5, cw).backward()
+        with torch.no_grad():
+            O.adamw_step([s5[k] for k in keys], [s5[k].grad for k in keys], m5, v5, n5[0], lr=1e-3, weight_decay=1e-3)
+    tb = timed(ce_step)
+    res["cases"] = {
+        "a_camera_encoder_eval_forward_4x3x224x224": {"value": round(4 / ta, 2), "unit": "frames/s", "ms_per_forward": round(ta * 1e3, 2),
+                                                      "sample": "10 timed forwards after 3 warm-ups"},
+        "b_ce_train_step_B4_N5000": {"value": round(B / tb, 3), "unit": "frames/s", "ms_per_step": round(tb * 1e3, 1),
+                                     "sample": f"10 timed steps after 3 warm-ups, {student_fusion} student, weighted CE + AdamW"},
+        "c_kd_train_step_B4_N%d" % N: {"value": res["value"], "unit": "frames/s", "ms_per_step": round(dt * 1e3, 1), "sample": "the headline sample above"}}
+    return res
 
 
 def bf16_forward_bench(args, dev, images, pts, steps):
@@ -167,6 +205,32 @@ def bf16_forward_bench(args, dev, images, pts, steps):
             "steps": steps, "per_gpu_batch": args.batch, "points_per_frame": args.points,
             "max_abs_logit_error_vs_fp32": float(f"{float((z16 - z32).abs().max()):.3e}"), "logit_range": float(f"{rng:.4g}"),
             "argmax_agreement_vs_fp32": round(float((z16.argmax(1) == z32.argmax(1)).float().mean()), 5)}
+
+
+def side_rate(args, dev, student_fusion, batch, steps, graph=False):
+    """frames/s of a KD step of another configuration (same teacher, points, image), fresh models; outside the timed headline."""
+    from kdrt import gradsink
+    from kdrt.kd import GraphedKDStep, KDStep
+    from kdrt.optim import FusedAdamW
+    teacher, student = build_models(args.grid, args.teacher_fusion, student_fusion)
+    teacher, student = teacher.to(dev).eval(), student.to(dev).train()
+    opt = FusedAdamW(student.parameters(), lr=1e-3, weight_decay=1e-3)
+    step = KDStep(student, teacher, opt, torch.tensor([0.4, 3.5], device=dev), T=4.0, alpha=1.0, beta=1.0)
+    images, pts, labels = synth_batch(batch, args.points, args.image, args.grid, 1234, dev, args.points_sigma)
+    run = GraphedKDStep(step, images, pts, labels) if graph else (lambda: step(images, pts, labels))
+    for _ in range(2):
+        parts = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        parts = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ok = bool(torch.isfinite(parts["total"]).item())
+    del run, step, opt, teacher, student, images, pts, labels
+    gradsink.uninstall()
+    torch.cuda.empty_cache()
+    return {"value": round(batch / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "finite": ok}
 
 
 def kernel_code_state():
@@ -272,6 +336,8 @@ def main():
     ap.add_argument("--no-selfcheck", action="store_true")
     ap.add_argument("--dump-launches", default=None, help="write the profiled GEMM launches one per line to this file")
     ap.add_argument("--no-bf16-forward", action="store_true", help="skip the bf16-storage forward line (configs[1])")
+    ap.add_argument("--no-side-benches", action="store_true",
+                    help="skip the fusion-ablation (configs[4]) and small-batch (B=4 eager / hipGraph) lines of the N=1 run")
     ap.add_argument("--force-reducer", action="store_true",
                     help="--gpus 1 only: bring up RCCL with a world of one rank and run the timed steps WITH the bucketed "
                          "gradient all-reduce (a one-rank sum: same bits), then time the same steps without it and report the delta")
@@ -361,6 +427,8 @@ def main():
         if i == 0:
             first = parts
     barrier()
+    if reducer is not None:
+        reducer.exposed = []                                  # event pairs around the waits of finish(): see the `comm` block
     t0 = time.perf_counter()
     for _ in range(args.steps):
         parts = step(images, pts, labels)
@@ -368,6 +436,16 @@ def main():
             first = parts
     barrier()
     elapsed = time.perf_counter() - t0
+    comm = None
+    if reducer is not None:
+        # exposed all-reduce time: how long the COMPUTE stream sat in the waits of reducer.finish() (HIP events recorded on it
+        # right before and right after the waits); 0 when the reductions finished under the rest of backward
+        ev, reducer.exposed = reducer.exposed, None
+        exposed_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        comm = {"bucket_bytes": [int(v.numel() * 4) for v in reducer.views], "buckets_per_step": len(reducer.views),
+                "collectives_per_step": reducer.collectives_issued / max(args.warmup + args.steps, 1),
+                "allreduce_exposed_ms_per_step": round(exposed_ms, 4), "steps_measured": len(ev),
+                "how": "HIP events on the compute stream around the work.wait() calls of BucketedAllReduce.finish(), timed steps only"}
     # outputs of the timed region must be numbers: step-0 and last-step losses, every parameter and moment finite
     first_losses = {k: float(first[k]) for k in ("total", "ce", "kl", "mse_cam", "mse_lidar")}
     last_losses = {k: float(parts[k]) for k in ("total", "ce", "kl", "mse_cam", "mse_lidar")}
@@ -405,6 +483,12 @@ def main():
     }
     if rank_info is not None:
         out.update(rank_info)
+    if comm is not None:
+        if world > 1:
+            t = torch.tensor([comm["allreduce_exposed_ms_per_step"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            comm["allreduce_exposed_ms_per_step_max_over_ranks"] = round(float(t.item()), 4)
+        out["comm"] = comm
     if world > 1:
         out["cpu_baseline"] = None
         out["bf16_forward"] = None
@@ -471,9 +555,22 @@ def main():
         # fp32-equivalent FLOP/s (2MKN) and the bf16 FLOP/s actually executed (6 piece products per product).
         gbps = g[1] / g[2] / 1e9
         tf = g[0] / g[2] / 1e12
+        # Headline fraction: the roofline north_star words its target in -- the camera-side convolution
+        # GEMMs (encoder, FPN, fusion, head; forward + data gradient + weight gradient) against the per-launch roofline
+        # max(FLOP / matrix-pipe peak, bytes / HBM peak) summed over their launches.  `achieved` = their fp32-equivalent
+        # TFLOP/s, `peak` = the TFLOP/s the same launches would reach if each ran exactly at its own floor, frac = achieved /
+        # peak.  The HBM-only view of the forward / data-gradient family (rounds 1-3's headline) stays beside it in `hbm_only`.
+        cam = groups.get("camera_fpn_fusion_head", [0.0, 0.0, 1e-9, 1e-12, 0])
+        cam_frac = cam[3] / cam[2]
+        cam_tf = cam[0] / cam[2] / 1e12
         out["roofline"] = {
-            "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+            "bound": "mixed", "achieved": round(cam_tf, 2), "peak": round(cam_tf / max(cam_frac, 1e-9), 2), "unit": "TFLOP/s",
+            "frac": round(cam_frac, 4), "traffic": None,
+            "what": "camera / FPN / fusion / head 1x1-convolution GEMMs (fwd + dgrad + wgrad launches of two profiled steps): sum of per-launch "
+                    "floors max(2MKN*6 / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s) over their HIP-event time; fp32-equivalent TFLOP/s",
+            "mfma_busy_pct": None,
+            "hbm_only": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                         "what": "forward + data-gradient GEMM family incl. the point-MLP forward layers: algorithmic bytes / launch time"},
             "kernel": "pw_stream_kernel<KB,NB,PRO,EPI> / pw_gemm_kernel<PRO,EPI> (1x1-conv fwd + dgrad incl. the point-MLP forward layers, weight-resident streaming form where the shape allows, tiled form otherwise; " +
                       ("bf16x6 split products on v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if arith == "split"
                        else "v_mfma_f32_32x32x2_f32)"),
@@ -506,7 +603,14 @@ def main():
                 "replaces": "kd_lidar_l2_dgrad + _l2_wgrad + _l1_dgrad + _l1_wgrad: 21.8 ms and 94 GB of operand passes per step in round 2"}
         # HBM bytes per launch come from PMC counters, which need their own rocprofv3 passes: use the committed
         # measurement of this exact workload (profiles/), null for any other configuration
-        for fn in ("r03_bench_pmc_traffic_B256.json", "r02_bench_pmc_traffic_B256.json", "r01_bench_pmc_traffic_B256.json"):
+        try:   # matrix-pipe busy % of the camera GEMM kernels inside the step: a committed PMC measurement, tagged with its kernel hash
+            mu = json.load(open(os.path.join(ROOT, "profiles", "r04_camera_gemm_mfma_busy.json")))
+            out["roofline"]["mfma_busy_pct"] = mu["camera_gemm_mfma_busy_pct"]
+            out["roofline"]["mfma_busy_detail"] = {k: mu[k] for k in ("by_kernel", "how", "kernel_hash") if k in mu}
+            out["roofline"]["mfma_busy_is_current"] = mu.get("kernel_hash") == kernel_code_state()
+        except (OSError, KeyError, ValueError):
+            pass
+        for fn in ("r04_bench_pmc_traffic_B256.json", "r03_bench_pmc_traffic_B256.json", "r02_bench_pmc_traffic_B256.json", "r01_bench_pmc_traffic_B256.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 wl = pmc["workload"]
@@ -551,6 +655,17 @@ def main():
         del step
         torch.cuda.empty_cache()
         out["bf16_forward"] = bf16_forward_bench(args, dev, images, pts, max(3, min(args.steps, 10)))
+    if rank == 0 and world == 1 and not args.no_side_benches:
+        # configs[4] (fusion ablation under the same concat teacher) and the reference's own batch size (B=4: launch-bound;
+        # eager and as one replayed hipGraph).  Bounded: 5 timed steps per student at the benchmarked batch, 20 at B=4.
+        torch.cuda.empty_cache()
+        ns = max(3, min(args.steps, 5))
+        out["ablation"] = {"what": f"KD step frames/s per student fusion, {args.teacher_fusion} teacher, B={args.batch}, same box, {ns} timed steps each (configs[4])"}
+        for sf in ("concat", "minimal", "weighted"):
+            out["ablation"][sf] = side_rate(args, dev, sf, args.batch, ns)
+        out["small_batch"] = {"what": f"the reference's batch (B=4), {args.student_fusion} student, N={args.points} points: eager launches vs the whole step as one replayed hipGraph, 20 timed steps each",
+                              "B4_eager": side_rate(args, dev, args.student_fusion, 4, 20),
+                              "B4_hipgraph": side_rate(args, dev, args.student_fusion, 4, 20, graph=True)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(teacher, student, args.points, args.image, args.grid, args.teacher_fusion, args.student_fusion)
     if rank == 0:

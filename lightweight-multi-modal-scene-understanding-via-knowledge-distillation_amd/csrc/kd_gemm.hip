@@ -548,42 +548,7 @@ __global__ __launch_bounds__(256, SPLIT ? ((WM == 2 && PRO != 2 && PRO != 3 && P
 // wgrad: dW[n][k] = sum_m Deff[m][n] * Aeff[m][k].  Output tile (64*WN) x (64*WK); WM waves split
 // the rows of each staged chunk; the grid additionally splits M into `nsplit` slices whose partial
 // tiles go to a slab [nsplit][N][K] summed in fixed order by wgrad_reduce_kernel (deterministic).
-struct WgradArgs {
-  const float* D; int64_t ldd;        // dY raw gradient or G (d_mode 2)
-  const float* X; int64_t ldx;        // d_mode 2: raw conv output X[M,N]
-  const float* al; const float* be; const float* ga; const float* msc; const float* msh; int d_mode; int d_act;
-  const float* A; int64_t lda;        // raw input activations [M,K]
-  const float* asc; const float* ash; int a_mode; int a_act;
-  float* slab;                        // [nsplit][N][K]
-  int M, N, K;
-  int rows_per_split;                 // multiple of the chunk height
-  const float* l0w; const float* l0b; // AMODE 2: A = act(bn(layer0(point))), g.A = points [M,4]
-  // DMODE 3: D = Y raw (also the BN-backward X); the scatter-max gradient G is rebuilt from trows / tmx / tshare exactly
-  // as in pw_gemm_kernel PRO4 (msc / msh / d_act = Y's BatchNorm + activation)
-  const float* tmx; const float* tshare; const int* trows;
-  int xcd_order;                      // 1: the output tiles of one row slice go to blocks that share an XCD (see the kernel)
-};
-
-//
-// SPLIT (same arithmetic as pw_gemm_kernel<.., SPLIT>): the reduction index of this GEMM is the matrix ROW m, so the
-// MFMA operands are COLUMNS of the staged tiles.  The bf16 planes stay row-major [m][n] in LDS (8-byte stores, as
-// loaded) and the fragments are fetched with ds_read_b64_tr_b16, gfx950's transposing LDS read: a 16-lane group reads
-// a 4-row x 16-column block and each lane receives one column of it -- four consecutive m for its n.  Rows are padded
-// by 32 bf16 so that the four 64-byte row segments of a block fall in four different bank quarters.
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-
-__device__ __forceinline__ bf16x8 kd_tr_frag(const unsigned short* plane, int ld, int row0, int col0, int lane) {
-  // fragment of the 32(col) x 16(row) operand block at (row0, col0): lane (r = lane & 31, h = lane >> 5) gets rows
-  // row0 + 8h .. +7 of column col0 + r
-  const int grp = lane >> 4, li = lane & 15;
-  const unsigned short* p0 = plane + (row0 + 8 * (grp >> 1) + (li >> 2)) * ld + col0 + 16 * (grp & 1) + 4 * (li & 3);
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * ld));
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
+// (WgradArgs and kd_tr_frag: kd_gemm_args.h -- shared with the role-specialised form in kd_wgrad_rs.hip)
 // timing-only probes of dev builds (-DKD_WG_PROBE=bits; results WRONG by construction): 1 one of the six piece products, 2 every chunk
 // loads the slice's FIRST rows (operands stay cache-resident: no HBM latency)
 #ifndef KD_WG_PROBE
@@ -947,6 +912,9 @@ int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st, int64_t partial_r
 int wgrad_launch(WgradArgs& g, size_t ws_bytes, float* dW, hipStream_t st) {
   const int N = g.N, K = g.K;
   if (g_gemm_split.load(std::memory_order_relaxed)) {
+    const int rc = kd_wgrad_rs_launch(g, ws_bytes, dW, st);      // the role-specialised form where the layer has one (kd_wgrad_rs.hip)
+    if (rc < 0) return KD_ERR_ARG;
+    if (rc > 0) return KD_OK;
     if (N > 64 && K > 64) return launch_wgrad<2, 2, 1, true>(g, ws_bytes, dW, st);
     if (N > 64) return launch_wgrad<2, 1, 2, true>(g, ws_bytes, dW, st);
     if (K > 64) return launch_wgrad<1, 2, 2, true>(g, ws_bytes, dW, st);
@@ -1014,11 +982,11 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
 }
 
 size_t kd_pwconv_wgrad_ws_bytes(int64_t M, int N, int K) {
-  (void)M;
   const int tn = N > 64 ? 128 : 64, tk = K > 64 ? 128 : 64;
   const int ntiles = ((N + tn - 1) / tn) * ((K + tk - 1) / tk);
   const int nsplit = (512 + ntiles - 1) / ntiles;
-  return (size_t)nsplit * (size_t)N * (size_t)K * sizeof(float);
+  const size_t tiled = (size_t)nsplit * (size_t)N * (size_t)K * sizeof(float), rs = kd_wgrad_rs_ws_bytes(M, N, K);
+  return tiled > rs ? tiled : rs;
 }
 
 int kd_pwconv_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, int d_mode, int d_act, const float* al,

@@ -61,6 +61,9 @@ class BucketedAllReduce:
             raise RuntimeError("BucketedAllReduce(force=True) needs an initialised process group (a world of one rank is fine)")
         self.enabled = True
         self.collectives_issued = 0       # all-reduce calls handed to torch.distributed so far (tests / bench read it)
+        # set to a list to measure the EXPOSED all-reduce time: finish() then records a HIP-event pair on the compute stream
+        # around its waits (the stream sits between them exactly as long as a reduction is still running); bench.py's `comm`
+        self.exposed: Optional[list] = None
         n = len(flat.params)
         # bucket boundaries (parameter indices), contiguous in registration order; cut where the
         # top-level module name changes, then merged down to n_buckets of similar byte size
@@ -132,7 +135,15 @@ class BucketedAllReduce:
         for b in range(len(self.spans)):
             if self.pending[b] > 0:
                 self._launch(b)
-        for h in self.handles:
-            h.wait()
+        if self.exposed is not None and self.handles and torch.cuda.is_available():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for h in self.handles:
+                h.wait()
+            e1.record()
+            self.exposed.append((e0, e1))
+        else:
+            for h in self.handles:
+                h.wait()
         self.reset()
         return 1.0 / self.world           # the factor the optimiser applies to the summed gradients

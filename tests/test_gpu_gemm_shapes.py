@@ -89,6 +89,45 @@ def test_dgrad_and_wgrad(M, K, N):
     _close(dW, dy.t() @ aeff, "wgrad")
 
 
+@pytest.mark.parametrize("M,N,K", [(5000, 192, 32), (4133, 384, 64), (3001, 768, 128), (2500, 64, 192), (2222, 64, 384), (1999, 128, 384),
+                                   (3100, 128, 768), (1000, 128, 128), (900, 128, 64), (777, 64, 128), (1500, 128, 256), (1800, 256, 256),
+                                   (650, 64, 256), (17, 384, 64), (40000, 384, 64)])
+@pytest.mark.parametrize("d_mode,a_mode", [(0, 0), (2, 1), (2, 0), (0, 1)])
+def test_role_specialised_wgrad_against_fp64_and_the_tiled_kernel(M, N, K, d_mode, a_mode):
+    """kd_wgrad_rs.hip (one workgroup per CU owns a block of dW; vector waves convert, matrix waves multiply; column slices for
+    the 768-wide layers; row slices with tail chunks) against an fp64 reference and against pw_wgrad_kernel."""
+    from kdrt import ops
+    if ops.get_gemm_arithmetic() != "split":
+        pytest.skip("the role-specialised weight gradient exists in the split arithmetic only")
+    g = torch.Generator().manual_seed(M + 7 * N + 13 * K + d_mode + 3 * a_mode)
+    c = lambda t: t.cuda()
+    G, Y, A = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g), torch.randn(M, K, generator=g)
+    al, be, ga = (torch.randn(N, generator=g) * 0.5 for _ in range(3))
+    msc, msh = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
+    asc, ash = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
+    d = lambda t: t.double()
+    dy = d(G) if d_mode == 0 else d(al) * (d(G) * ((d(Y) * d(msc) + d(msh)) > 0).double()) + d(be) * d(Y) + d(ga)
+    aeff = d(A) if a_mode == 0 else (d(A) * d(asc) + d(ash)).clamp_min(0)
+    want = dy.t() @ aeff
+
+    def run():
+        dW = torch.full((N, K), float("nan"), device="cuda")
+        ops.pw_wgrad(c(G), c(A), dW, M=M, N=N, K=K, X=c(Y) if d_mode == 2 else None, d_mode=d_mode, d_act=1, al=c(al), be=c(be), ga=c(ga),
+                     msc=c(msc), msh=c(msh), a_mode=a_mode, a_act=1, asc=c(asc), ash=c(ash))
+        torch.cuda.synchronize()
+        return dW
+    prev = ops.lib.kd_set_wgrad_rs(0)
+    try:
+        tiled = run()
+        ops.lib.kd_set_wgrad_rs(1)
+        rs = run()
+    finally:
+        ops.lib.kd_set_wgrad_rs(prev)
+    _close(rs, want, "rs wgrad")
+    _close(tiled, want, "tiled wgrad")
+    assert (rs - tiled).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
 def _both_forms(fn):
     """Run fn() with the tiled kernels, then with the streaming kernels; returns the two results."""
     from kdrt import ops
@@ -103,7 +142,7 @@ def _both_forms(fn):
 
 
 @pytest.mark.parametrize("M,K,N", [(2100, 32, 32), (640, 64, 192), (777, 128, 128), (1000, 64, 384), (333, 384, 64), (129, 768, 128),
-                                   (450, 256, 128), (5000, 192, 32)])
+                                   (450, 256, 128), (5000, 192, 32), (1000, 32, 192), (700, 64, 384), (333, 64, 192), (4099, 64, 384)])
 @pytest.mark.parametrize("epi,with_addend", [(0, False), (0, True), (2, False), (2, True)])
 def test_streaming_dgrad_same_bits_as_tiled(M, K, N, epi, with_addend):
     """The streaming form of the data gradient (PRO2 operand from two streamed tensors, K chunks, several column tiles,

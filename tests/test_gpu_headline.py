@@ -111,9 +111,10 @@ def test_headline_frame_shape_kd_step_against_the_reference():
     for k in names:                                   # every tensor: its norm against the float64 norm (|‖a‖-‖b‖| <= ‖a-b‖)
         if norm64[k] < 1e-6 * gmax:
             continue                                  # conv biases in front of a train-mode BatchNorm: true gradient 0
-        d = abs(grads[k].norm().item() - norm64[k]) / norm64[k]
-        if d > 3 * ref_err[k] + 1e-5:
-            bad.append((k, d, ref_err[k]))
+        d = abs(grads[k].norm().item() - norm64[k])
+        # (absolute floor: the 2-element attention bias is a cancelling sum of norm 4e-4 -- its fp32 error is rounding of the terms)
+        if d > (3 * ref_err[k] + 1e-5) * norm64[k] + 2e-5 * gmax:
+            bad.append((k, d / norm64[k], ref_err[k]))
     assert not bad, bad
 
 
@@ -125,10 +126,10 @@ def test_headline_frame_shape_plain_ce_step_against_the_reference():
     loss, _ = seg_loss(logits, labels.cuda(), torch.tensor([0.4, 3.5]).cuda())
     loss.backward()
     assert abs(loss.item() - float(gd["ce_step_loss"])) < TOL
-    names = [str(k) for k in gd["grad_keys"]]
+    gmax = float(gd["ce_grad_digest"][:, 1].max())
     for (n, p), want in zip(student.named_parameters(), gd["ce_grad_digest"]):
-        if want[1] < 1e-7:
-            continue
+        if want[1] < 1e-5 * gmax:
+            continue                   # conv biases in front of a train-mode BatchNorm: the true gradient is 0, both sides hold rounding noise
         assert abs(p.grad.norm().item() - want[1]) <= 2e-2 * want[1], (n, p.grad.norm().item(), want[1])
     from kdrt.losses import confusion
     safe = torch.from_numpy(np.abs(gd["student_logits"][:, 0] - gd["student_logits"][:, 1]) > 4 * TOL)

@@ -25,6 +25,9 @@ int main(int argc, char** argv) {
       {"stage1 pw 32->32", scale * 16384, 32, 32, 0}, {"stage5-ish 128->64", scale * 4096, 128, 64, 0},
       {"fpn 64->128", scale * 4096, 64, 128, 0}, {"fpn/fusion 128->128", scale * 4096, 128, 128, 0},
       {"head 64->32", scale * 4096, 64, 32, 0}, {"stage5 expand 128->768", scale * 1024, 128, 768, 0},
+      {"stage2 project 192->64", scale * 4096, 192, 64, 0}, {"stage3 project 384->64", scale * 4096, 384, 64, 0},
+      {"stage4 project 384->128", scale * 1024, 384, 128, 0}, {"head 256->64", scale * 4096, 256, 64, 0},
+      {"attention 256->128", scale * 4096, 256, 128, 0}, {"odd M 384->64", 100003, 384, 64, 0},
       {"odd M 128->128", 100003, 128, 128, 0}, {"tiny M 64->128", 77, 64, 128, 0}};
   size_t big = 0;
   for (auto& s : shapes) big = std::max(big, (size_t)s.M * std::max(s.K, s.N));
@@ -108,7 +111,9 @@ int main(int argc, char** argv) {
   struct DShape { const char* name; long M; int K, N; };     // K = reduction width (the layer's output channels), N = its input channels
   std::vector<DShape> dshapes = {{"stage1 project 32<-32", scale * 16384, 32, 32}, {"stage3 project 384<-64", scale * 4096, 64, 384},
                                  {"stage5 project 768<-128", scale * 1024, 128, 768}, {"fpn/fusion 128<-128", scale * 4096, 128, 128},
-                                 {"head 128<-64", scale * 4096, 64, 128}, {"odd M 128<-128", 100003, 128, 128}};
+                                 {"head 128<-64", scale * 4096, 64, 128}, {"odd M 128<-128", 100003, 128, 128},
+                                 {"stage2 expand 32<-192", scale * 16384, 192, 32}, {"stage3 expand 64<-384", scale * 4096, 384, 64},
+                                 {"odd M 64<-384", 100003, 384, 64}};
   float *al = vec + 8192, *be = vec + 9216, *ga = vec + 10240, *mean = vec + 11264, *inv = vec + 12288;
   for (auto& s : dshapes) {
     const double fl = 2.0 * s.M * s.K * s.N;
