@@ -54,7 +54,7 @@ const char* kd_last_error_string(void);
 int kd_set_gemm_split(int on);
 int64_t kd_pwconv_stat_rows(int64_t M);
 int64_t kd_pwconv_stat_rows_for(int64_t M, int K, int N, int pro, int epi, int with_addend);
-/* Rows of the statistics slab the launch for (K, N, pro, epi, addend given or not) will write in the current arithmetic (one per wave for the
+/* Rows of the statistics slab the launch for (K, N, pro, epi, addend given or not) will write in the current arithmetic (one per workgroup for the
  * weight-resident streaming kernels of kd_gemm_stream.hip, one per 128 matrix rows for the tiled kernels): size the slab and
  * drive kd_bn_finalize_train / kd_bn_bwd_finalize with it.  kd_set_gemm_stream: 0 = tiled kernels only, 1 = streaming
  * kernels only for the shapes that win in isolation, 2 = every covered shape (default; env KD_GEMM_STREAM=0|1|all), 3 = every covered forward shape, tiled data gradients;
@@ -164,7 +164,7 @@ int kd_lidar_l1_dgrad(const float* G, int64_t ldg, const float* Y1, int64_t ldy,
  * G0 may be NULL and the [points, K0] gradient is never written.  m1_ws: kd_lidar_l1_dgrad_ws_bytes. */
 size_t kd_lidar_l1_dgrad_ws_bytes(int64_t M, int K0);
 /* rows of the BatchNorm-backward slab (`partial`) kd_lidar_l1_dgrad / kd_lidar_l2_dgrad write for a shape in the current
- * arithmetic (one per wave when a streaming kernel takes the launch, one per 128 matrix rows otherwise) */
+ * arithmetic (one per workgroup when a streaming kernel takes the launch, one per 128 matrix rows otherwise) */
 int64_t kd_lidar_l1_dgrad_stat_rows(int64_t M, int N1, int K0);
 int64_t kd_lidar_l2_dgrad_stat_rows(int64_t M, int N2, int K1);
 int kd_lidar_l1_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, int d_act, const float* al,

@@ -858,7 +858,7 @@ int64_t stat_rows_for(int64_t M, int K, int N, int pro, int epi, bool add) {
 }
 
 // partial_rows: the row count the CALLER sized its statistics slab for (and will hand to kd_bn_finalize_train /
-// kd_bn_bwd_finalize).  The two kernel forms write different row counts (one per wave / one per 128 matrix rows), and
+// kd_bn_bwd_finalize).  The two kernel forms write different row counts (one per workgroup / one per 128 matrix rows), and
 // which form runs depends on process-wide switches that may have moved since the caller asked: a mismatch is an error
 // here, never a silently short or stale reduction downstream (round 2's 3e-4 systematic gradient error).
 int gemm_launch(GemmArgs& g, int pro, int epi, hipStream_t st, int64_t partial_rows = -1) {
@@ -947,7 +947,7 @@ int kd_dbg_read(unsigned long long* out, int reset) {
 // Rows of the BN-statistics slab a GEMM over M rows writes ([rows][2][N] floats).
 int64_t kd_pwconv_stat_rows(int64_t M) { return (M + BM - 1) / BM; }
 // ... for the launch the dispatcher will actually make for (K, N, pro, epi) in the current arithmetic: the streaming
-// kernels write one row per wave (<= 1024), the tiled kernels one per 128 matrix rows.  Callers size the slab AND tell
+// kernels write one row per workgroup (<= 256), the tiled kernels one per 128 matrix rows.  Callers size the slab AND tell
 // kd_bn_finalize_train / kd_bn_bwd_finalize how many rows to sum with this number.
 int64_t kd_pwconv_stat_rows_for(int64_t M, int K, int N, int pro, int epi, int with_addend) { return stat_rows_for(M, K, N, pro, epi, with_addend != 0); }
 

@@ -104,7 +104,7 @@ int fwd_dispatch(const GemmArgs& g, int pro, int epi, dim3 grid, hipStream_t st)
 int kd_gemm_stream_stat_rows(int64_t M, int K, int N, int pro, int epi, bool add) {
   StreamCfg c;
   if (!stream_cfg(K, N, pro, epi, add, c)) return 0;
-  return stream_grid(M, c.ntiles) * SW;
+  return stream_grid(M, c.ntiles);          // one row per workgroup (the waves' sums are combined in LDS)
 }
 
 int kd_gemm_stream_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {

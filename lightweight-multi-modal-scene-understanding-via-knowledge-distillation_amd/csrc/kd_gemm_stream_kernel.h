@@ -28,8 +28,9 @@
 //   * the accumulator tile goes to HBM directly: register q of a 32x32 block is one 128-byte row segment per half
 //     wave (full-rate dword stores); the data-gradient epilogue (EPI2) reads the raw tensor whose activation is
 //     differentiated in the same layout.  BatchNorm statistics are per-lane column sums kept in registers ACROSS the slabs
-//     of the wave and written once per launch: the statistics slab has one row per wave (<= 2048) instead of one per 128
-//     matrix rows (160 000 for the LiDAR layers), deterministic because the slab -> wave map is fixed.
+//     of the wave, combined over the workgroup's eight waves through LDS at the end and written once per launch: the statistics
+//     slab has one row per workgroup (<= 256) instead of one per 128 matrix rows (160 000 for the LiDAR layers), deterministic
+//     because the slab -> wave map and the order of the final sum are fixed.
 //
 // Arithmetic: identical to pw_gemm_kernel<.., SPLIT = true> (same pieces, same six products in the same order per
 // k-step, k-steps in order), so the raw outputs are bit-identical to the tiled kernel's; statistics are summed in a
@@ -385,14 +386,27 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
   }
 #endif
 
-  if (EPI == 1 || EPI_BWD) {        // one statistics row per wave: [wid][2][N_total]
+  if (EPI == 1 || EPI_BWD) {
+    // one statistics row per WORKGROUP (round 4; one per wave before): the eight waves' column sums meet in LDS -- the weight
+    // planes are dead once every wave has left its slab loop -- and are added in wave order (fixed: deterministic).  The slab
+    // the BatchNorm finalize walks shrinks from 2048 to at most 256 rows: that kernel is latency-bound on the rows per lane.
+    kd_lds_barrier();
+    float* red = reinterpret_cast<float*>(smem_raw);                       // [SW][2][N]
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64), t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
       if (h == 0) {
-        g.partial[(wid * 2 + 0) * g.N + n0 + 32 * j + r] = t1;
-        g.partial[(wid * 2 + 1) * g.N + n0 + 32 * j + r] = t2;
+        red[(wave * 2 + 0) * N + 32 * j + r] = t1;
+        red[(wave * 2 + 1) * N + 32 * j + r] = t2;
       }
+    }
+    kd_lds_barrier();
+    for (int i = tid; i < 2 * N; i += 64 * SW) {
+      const int st = i / N, c = i % N;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < SW; ++w) t += red[(w * 2 + st) * N + c];
+      g.partial[((int64_t)blockIdx.x * 2 + st) * g.N + n0 + c] = t;
     }
   }
 }

@@ -261,8 +261,19 @@ bool rs_plan(int N, int K, RsPlan& p) {
       {4, 8, 2, 4, 2, 2, 1},    // 128 x 256  attention conv; 256 x 256 concat fuse (2 slices)
       {2, 8, 1, 4, 2, 2, 2},    // 64 x 256   head block 0 (concat)
   };
+  // Measured per layer at 256 frames against pw_wgrad_kernel (tools/bench_wgrad.py, profiles/r04_wgrad_rs_ab.txt): x1.28 (192 x 32),
+  // x1.08-1.10 (384 x 64, 768 x 128, 64 x 384), x1.20 (128 x 384), x1.02 (128 x 768), x1.04 (128 x 256), x1.13 (256 x 256); it LOSES
+  // on 64 x 192 (x0.95), 128 x 128 (x0.91), 64 x 256 (x0.97) and ties on 64 x 128 / 128 x 64 -- those stay on the tiled kernel
+  // unless KD_WGRAD_RS=all.
+  static const bool all = [] { const char* e = getenv("KD_WGRAD_RS"); return e && e[0] == 'a'; }();
   for (const E& e : tab)
-    if (e.nb == nb && e.kb == kb) { p = {e.tnw, e.tkw, e.wn, e.wk, e.chk, ncs, split_n}; return true; }
+    if (e.nb == nb && e.kb == kb) {
+      const bool wins = (nb == 6 && kb == 1) || (nb == 12 && kb == 2) || (nb == 8 && kb == 4) || (nb == 2 && kb == 6 && ncs == 2) ||
+                        (nb == 4 && kb == 6) || (nb == 4 && kb == 8);
+      if (!wins && !all) return false;
+      p = {e.tnw, e.tkw, e.wn, e.wk, e.chk, ncs, split_n};
+      return true;
+    }
   return false;
 }
 

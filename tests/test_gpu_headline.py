@@ -130,7 +130,8 @@ def test_headline_frame_shape_plain_ce_step_against_the_reference():
     for (n, p), want in zip(student.named_parameters(), gd["ce_grad_digest"]):
         if want[1] < 1e-5 * gmax:
             continue                   # conv biases in front of a train-mode BatchNorm: the true gradient is 0, both sides hold rounding noise
-        assert abs(p.grad.norm().item() - want[1]) <= 2e-2 * want[1], (n, p.grad.norm().item(), want[1])
+        # (absolute floor: the 2-element attention bias is a cancelling sum -- two entries +-7.7e-6 -- whose error is the rounding of its terms)
+        assert abs(p.grad.norm().item() - want[1]) <= 2e-2 * want[1] + 2e-5 * gmax, (n, p.grad.norm().item(), want[1])
     from kdrt.losses import confusion
     safe = torch.from_numpy(np.abs(gd["student_logits"][:, 0] - gd["student_logits"][:, 1]) > 4 * TOL)
     conf, _ = confusion(logits, torch.where(safe, labels, torch.full_like(labels, -1)).cuda())
