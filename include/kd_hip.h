@@ -74,10 +74,11 @@ int kd_pwconv_gemm(const float* A, int64_t lda, const float* A2, int64_t lda2, i
 /* weight gradient dW[N,K] = Deff[M,N]^T . Aeff[M,K] (split-M partial tiles in `ws`, fixed-order sum).
  * d_mode 0: Deff = D; d_mode 2: Deff = al*(D*mask(X*msc+msh)) + be*X + ga.  a_mode 0/1 like pro 0/1. */
 size_t kd_pwconv_wgrad_ws_bytes(int64_t M, int N, int K);
-/* 1 (default; env KD_WGRAD_RS=0 starts with 0): layers with a role-specialised instance (csrc/kd_wgrad_rs.hip: one workgroup per CU owns a
- * whole block of dW, vector waves load / convert, matrix waves multiply) use it; 0: the tiled kernel everywhere.  Split
- * arithmetic only.  Returns the previous setting.  kd_pwconv_wgrad_ws_bytes answers for the larger of the two forms. */
-int kd_set_wgrad_rs(int on);
+/* Weight-gradient kernel form (split arithmetic only).  1 (default): layers where the role-specialised kernel (csrc/kd_wgrad_rs.hip: one
+ * workgroup per CU owns a whole block of dW, vector waves load / convert, matrix waves multiply) measured faster use it; 2 (env
+ * KD_WGRAD_RS=all): every layer that has an instance; 0 (KD_WGRAD_RS=0): the tiled kernel everywhere.  Returns the previous mode.
+ * kd_pwconv_wgrad_ws_bytes answers for the larger of the two forms whatever the mode. */
+int kd_set_wgrad_rs(int mode);
 int kd_pwconv_wgrad(const float* D, int64_t ldd, const float* X, int64_t ldx, int d_mode, int d_act,
                     const float* al, const float* be, const float* ga, const float* msc, const float* msh,
                     const float* A, int64_t lda, int a_mode, int a_act, const float* asc, const float* ash,

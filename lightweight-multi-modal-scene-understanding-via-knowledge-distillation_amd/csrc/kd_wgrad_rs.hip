@@ -236,11 +236,22 @@ __global__ __launch_bounds__(RS_THREADS, 1) void pw_wgrad_rs_kernel(WgradArgs g,
   }
 }
 
+std::atomic<int> g_rs_on{-1};       // 0 off, 1 the layers where it measured faster (default), 2 every layer with an instance
+int rs_mode() {
+  int v = g_rs_on.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("KD_WGRAD_RS");
+    v = (e && e[0] == '0') ? 0 : ((e && e[0] == 'a') ? 2 : 1);
+    g_rs_on.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 // ---- configuration table ------------------------------------------------------------------------------------------------
 struct RsPlan { int tnw, tkw, wn, wk, chk, ncs, split_n; };
 
 // (N / 32, K / 32) -> plan; false: not covered (tiny layers, odd widths: the tiled kernel serves them)
-bool rs_plan(int N, int K, RsPlan& p) {
+bool rs_plan(int N, int K, RsPlan& p, bool any = false) {
   if (N % 32 || K % 32) return false;
   int nb = N / 32, kb = K / 32, ncs = 1, split_n = 0;
   // the 768-wide operand is cut into column slices so that a workgroup's block of dW fits its accumulator registers
@@ -264,8 +275,8 @@ bool rs_plan(int N, int K, RsPlan& p) {
   // Measured per layer at 256 frames against pw_wgrad_kernel (tools/bench_wgrad.py, profiles/r04_wgrad_rs_ab.txt): x1.28 (192 x 32),
   // x1.08-1.10 (384 x 64, 768 x 128, 64 x 384), x1.20 (128 x 384), x1.02 (128 x 768), x1.04 (128 x 256), x1.13 (256 x 256); it LOSES
   // on 64 x 192 (x0.95), 128 x 128 (x0.91), 64 x 256 (x0.97) and ties on 64 x 128 / 128 x 64 -- those stay on the tiled kernel
-  // unless KD_WGRAD_RS=all.
-  static const bool all = [] { const char* e = getenv("KD_WGRAD_RS"); return e && e[0] == 'a'; }();
+  // unless kd_set_wgrad_rs(2) / KD_WGRAD_RS=all (tests exercise every instance that way).
+  const bool all = any || rs_mode() == 2;
   for (const E& e : tab)
     if (e.nb == nb && e.kb == kb) {
       const bool wins = (nb == 6 && kb == 1) || (nb == 12 && kb == 2) || (nb == 8 && kb == 4) || (nb == 2 && kb == 6 && ncs == 2) ||
@@ -296,16 +307,7 @@ int rs_launch_shape(const WgradArgs& g, const RsGeom& q, hipStream_t st) {
   return 0;
 }
 
-std::atomic<int> g_rs_on{-1};
-bool rs_enabled() {
-  int v = g_rs_on.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("KD_WGRAD_RS");
-    v = (e && e[0] == '0') ? 0 : 1;
-    g_rs_on.store(v, std::memory_order_relaxed);
-  }
-  return v != 0;
-}
+bool rs_enabled() { return rs_mode() != 0; }
 
 int rs_slices(int64_t M, const RsPlan& p) {
   const int ch = 16 * p.chk;
@@ -317,13 +319,13 @@ int rs_slices(int64_t M, const RsPlan& p) {
 
 }  // namespace
 
-extern "C" int kd_set_wgrad_rs(int on) { const bool prev = rs_enabled(); g_rs_on.store(on ? 1 : 0, std::memory_order_relaxed); return prev ? 1 : 0; }
+extern "C" int kd_set_wgrad_rs(int mode) { const int prev = rs_mode(); g_rs_on.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed); return prev; }
 
 // (sized for the role-specialised form whenever the layer HAS one, whatever the switches say now: a workspace allocated before a
 // switch flips must still fit)
 size_t kd_wgrad_rs_ws_bytes(int64_t M, int N, int K) {
   RsPlan p;
-  if (!rs_plan(N, K, p)) return 0;
+  if (!rs_plan(N, K, p, true)) return 0;
   return (size_t)rs_slices(M, p) * (size_t)N * (size_t)K * sizeof(float);
 }
 

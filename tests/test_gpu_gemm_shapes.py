@@ -119,7 +119,7 @@ def test_role_specialised_wgrad_against_fp64_and_the_tiled_kernel(M, N, K, d_mod
     prev = ops.lib.kd_set_wgrad_rs(0)
     try:
         tiled = run()
-        ops.lib.kd_set_wgrad_rs(1)
+        ops.lib.kd_set_wgrad_rs(2)                   # every layer that has an instance, also those the default leaves to the tiled kernel
         rs = run()
     finally:
         ops.lib.kd_set_wgrad_rs(prev)

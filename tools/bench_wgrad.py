@@ -25,7 +25,7 @@ for name, hw, K, N in shapes:
         ops.pw_wgrad(D, A, dW, M=M, N=N, K=K, X=X, d_mode=2, d_act=2, al=al, be=be, ga=ga, msc=msc, msh=msh, a_mode=1, a_act=2, asc=asc, ash=ash)
     res = []
     for form in (0, 1):                      # 0: tiled pw_wgrad_kernel, 1: role-specialised (kd_wgrad_rs.hip) where the layer has one
-        ops.lib.kd_set_wgrad_rs(form)
+        ops.lib.kd_set_wgrad_rs(2 * form)
         run(); run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
