@@ -247,6 +247,11 @@ int rs_mode() {
   return v;
 }
 
+bool rs_wide12() {
+  static const bool on = [] { const char* e = getenv("KD_WGRAD_RS_WIDE12"); return e && e[0] == '1'; }();
+  return on;
+}
+
 // ---- configuration table ------------------------------------------------------------------------------------------------
 struct RsPlan { int tnw, tkw, wn, wk, chk, ncs, split_n; };
 
@@ -256,7 +261,9 @@ bool rs_plan(int N, int K, RsPlan& p, bool any = false) {
   int nb = N / 32, kb = K / 32, ncs = 1, split_n = 0;
   // the 768-wide operand is cut into column slices so that a workgroup's block of dW fits its accumulator registers
   if (nb == 24) { nb = 8; ncs = 3; split_n = 1; }
+  else if (kb == 24 && nb == 4 && rs_wide12()) { kb = 12; ncs = 2; }
   else if (kb == 24) { kb = 6; ncs = 4; }
+  else if (kb == 12 && nb == 4 && rs_wide12()) { }
   else if (kb == 12 && nb <= 4) { kb = 6; ncs = 2; }
   else if (nb == 8 && kb == 8) { nb = 4; ncs = 2; split_n = 1; }
   struct E { int nb, kb, tnw, tkw, wn, wk, chk; };
@@ -266,6 +273,7 @@ bool rs_plan(int N, int K, RsPlan& p, bool any = false) {
       {8, 4, 2, 4, 4, 1, 1},    // 768 x 128  stage-5 expand (3 column slices of 256)
       {2, 6, 1, 3, 2, 2, 2},    // 64 x 192 stage-2 project; 64 x 384 stage-3 project (2 slices)
       {4, 6, 1, 6, 4, 1, 2},    // 128 x 384 stage-4 project (2 slices); 128 x 768 stage-5 project (4 slices)
+      {4, 12, 1, 12, 4, 1, 1},  // the same two layers with twelve k-blocks per wave (KD_WGRAD_RS_WIDE12=1): D converted once / twice instead of twice / four times
       {4, 4, 2, 2, 2, 2, 2},    // 128 x 128  FPN laterals / post, fusion projections
       {4, 2, 2, 1, 2, 2, 2},    // 128 x 64   FPN lateral of stage 3
       {2, 4, 1, 2, 2, 2, 2},    // 64 x 128   head block 0
@@ -279,7 +287,7 @@ bool rs_plan(int N, int K, RsPlan& p, bool any = false) {
   const bool all = any || rs_mode() == 2;
   for (const E& e : tab)
     if (e.nb == nb && e.kb == kb) {
-      const bool wins = (nb == 6 && kb == 1) || (nb == 12 && kb == 2) || (nb == 8 && kb == 4) || (nb == 2 && kb == 6 && ncs == 2) ||
+      const bool wins = (nb == 4 && kb == 12) || (nb == 6 && kb == 1) || (nb == 12 && kb == 2) || (nb == 8 && kb == 4) || (nb == 2 && kb == 6 && ncs == 2) ||
                         (nb == 4 && kb == 6) || (nb == 4 && kb == 8);
       if (!wins && !all) return false;
       p = {e.tnw, e.tkw, e.wn, e.wk, e.chk, ncs, split_n};
@@ -313,7 +321,7 @@ int rs_slices(int64_t M, const RsPlan& p) {
   const int ch = 16 * p.chk;
   int nrs = 256 / p.ncs;                                         // one workgroup per CU
   const int64_t chunks = (M + ch - 1) / ch;
-  if (nrs > chunks) nrs = (int)chunks;
+  if (nrs > chunks / 8) nrs = (int)(chunks / 8);                 // small batches: at least eight chunks per slice (fewer slab rows to reduce)
   return nrs < 1 ? 1 : nrs;
 }
 
@@ -345,6 +353,7 @@ int kd_wgrad_rs_launch(const WgradArgs& g0, size_t ws_bytes, float* dW, hipStrea
   int rc = 0;
 #define KD_RS_SHAPE(A_, B_, C_, D_, E_) if (p.tnw == A_ && p.tkw == B_ && p.wn == C_ && p.wk == D_ && p.chk == E_) rc = rs_launch_shape<A_, B_, C_, D_, E_>(g, q, st);
   KD_RS_SHAPE(3, 1, 2, 1, 2) KD_RS_SHAPE(3, 2, 4, 1, 1) KD_RS_SHAPE(2, 4, 4, 1, 1) KD_RS_SHAPE(1, 3, 2, 2, 2) KD_RS_SHAPE(1, 6, 4, 1, 2)
+  KD_RS_SHAPE(1, 12, 4, 1, 1)
   KD_RS_SHAPE(2, 2, 2, 2, 2) KD_RS_SHAPE(2, 1, 2, 2, 2) KD_RS_SHAPE(1, 2, 2, 2, 2) KD_RS_SHAPE(2, 4, 2, 2, 1) KD_RS_SHAPE(1, 4, 2, 2, 2)
 #undef KD_RS_SHAPE
   if (rc <= 0) return rc;

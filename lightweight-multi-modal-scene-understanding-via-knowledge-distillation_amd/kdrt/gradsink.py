@@ -23,10 +23,19 @@ class GradSink:
         for p, o in zip(flat.params, flat.offsets):
             self.views[id(p)] = (p, flat.grad[o:o + p.numel()].view(p.shape))
         self.written = set()
+        self.step_open = False         # True between begin_step() and end_step(): only then may feature gradients be routed
 
     def begin_step(self):
+        """Start of a training step that will check `pending()` after its backward pass (KDStep, Trainer._step).  Feature-gradient
+        routing (units.grad_routing) is enabled only while such a step is open: a plain `model(...); loss.backward()` loop that
+        merely inherited an installed sink never deposits addends nobody checks."""
         self.written.clear()
+        drop_pending()                 # nothing deposited by a step that failed half-way may leak into this one
+        self.step_open = True
         ops.TRANSPOSES.refresh()       # the parameters are final for this step: every W^T the data gradients need, one launch
+
+    def end_step(self):
+        self.step_open = False
 
     def buffer(self, p) -> Optional[torch.Tensor]:
         e = self.views.get(id(p))
@@ -48,7 +57,12 @@ class GradSink:
 # kernel of its projection as `addend`, so the sum of the two gradient paths is formed inside that kernel instead of by an
 # autograd accumulation pass over the map.  The depositor must check `pending()` is empty after backward (KDStep does): an
 # addend nobody collected would be a silently missing gradient term.
-_addends: Dict[int, torch.Tensor] = {}
+_addends: Dict[tuple, tuple] = {}
+
+
+def _key(mat: torch.Tensor):
+    # address AND shape: an address the caching allocator handed to an unrelated tensor after a failed step does not match by accident
+    return (mat.data_ptr(), tuple(mat.shape))
 
 
 def deposit(mat: torch.Tensor, grad: torch.Tensor, folded_residual: Optional[torch.Tensor] = None):
@@ -57,17 +71,17 @@ def deposit(mat: torch.Tensor, grad: torch.Tensor, folded_residual: Optional[tor
     gradient it actually received and corrects the sum if they differ (a third consumer of that output)."""
     if mat.shape != grad.shape or not grad.is_contiguous():
         raise RuntimeError("gradsink.deposit: the addend must be a contiguous tensor shaped like the feature matrix")
-    _addends[mat.data_ptr()] = (grad, folded_residual)
+    _addends[_key(mat)] = (grad, folded_residual)
 
 
 def collect(mat: torch.Tensor) -> Optional[torch.Tensor]:
-    e = _addends.pop(mat.data_ptr(), None) if _addends else None
+    e = _addends.pop(_key(mat), None) if _addends else None
     return None if e is None else e[0]
 
 
 def collect_flagged(mat: torch.Tensor):
     """-> (gradient, folded residual gradient or None) or None"""
-    return _addends.pop(mat.data_ptr(), None) if _addends else None
+    return _addends.pop(_key(mat), None) if _addends else None
 
 
 def pending() -> int:

@@ -73,6 +73,7 @@ class KDStep:
         finally:
             units.share_point_bins(False)  # ... and nothing of it outlives the two forward passes
         total, parts = self.objective_backward(zs, ms, zt, mt, labels)
+        self.sink.end_step()
         self.opt.grad_scale = self.reducer.finish() if self.reducer is not None else 1.0
         self.opt.step()
         parts["total"] = total
@@ -130,6 +131,7 @@ class GraphedKDStep:
         s.opt.zero_grad()
         zs, ms = s.student(self.images, self.points, return_intermediates=KD_FEATURES)
         total, parts = s.objective_backward(zs, ms, zt, mt, self.labels)
+        s.sink.end_step()
         s.opt.grad_scale = s.reducer.finish() if s.reducer is not None else 1.0
         s.opt.enqueue_update()
         parts["total"] = total

@@ -587,7 +587,7 @@ _GRAD_ROUTING = os.environ.get("KD_GRAD_ROUTING", "1") != "0"     # 0: two-consu
 def grad_routing(training: bool) -> bool:
     """May the encoder mark its two-consumer maps for gradient deposits (FPNFn.backward -> ChainFn.backward)?  Only inside a
     training step that checks `gradsink.pending()` after backward (a gradient sink is installed: KDStep, Trainer)."""
-    return bool(_GRAD_ROUTING and training and torch.is_grad_enabled() and gradsink.active is not None)
+    return bool(_GRAD_ROUTING and training and torch.is_grad_enabled() and gradsink.active is not None and gradsink.active.step_open)
 
 
 def chain_pair_ok(units_a: Sequence[UnitSpec], units_b: Sequence[UnitSpec], training: bool, out_w: int) -> bool:

@@ -121,8 +121,7 @@ class Trainer:
     # one optimisation step; overridden by KDTrainer
     def _step(self, imgs, pts, seg):
         gradsink.active = self.sink
-        gradsink.drop_pending()          # nothing deposited by an earlier step that failed half-way (a caught OOM) may leak into this one
-        self.sink.begin_step()
+        self.sink.begin_step()           # (also drops anything an earlier step that failed half-way -- a caught OOM -- left deposited)
         self.optimizer.zero_grad()
         logits = self.model(imgs, pts)
         loss = self.criterion(logits, seg)
@@ -130,6 +129,7 @@ class Trainer:
         if gradsink.pending():           # a feature-map gradient deposited for a later kernel that never ran: a missing gradient term
             gradsink.drop_pending()
             raise RuntimeError("a deposited feature gradient was not collected (kdrt.gradsink): unsupported model structure; set KD_GRAD_ROUTING=0")
+        self.sink.end_step()
         self.optimizer.grad_scale = self.reducer.finish() if self.reducer is not None else 1.0
         self.optimizer.step()
         return loss.detach(), logits.detach()

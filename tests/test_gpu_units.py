@@ -533,11 +533,11 @@ def test_chain_pairs_match_separate_chains(monkeypatch):
     for pairs in (True, False):
         monkeypatch.setattr(units, "_CHAIN_PAIRS", pairs)
         enc = TwinLiteEncoder(return_multiscale=True)
-        enc.unused_stages = ("stage2",)
         _rand_state(enc, 17)
         enc = enc.cuda().train()
-        maps = enc(x)
+        maps = enc(x, _skip_stages=("stage2",))                   # what CompleteSegmentationModel passes when its FPN does not read stage 2
         assert ("stage2" in maps) == (not pairs)
+        assert set(enc(x)) == {"stage2", "stage3", "stage4", "stage5"}     # called plainly: the reference's key set, always
         if up is None:
             up = {k: torch.randn(v.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) for k, v in maps.items()}
         sum((maps[k] * up[k]).sum() for k in ("stage3", "stage4", "stage5")).backward()
