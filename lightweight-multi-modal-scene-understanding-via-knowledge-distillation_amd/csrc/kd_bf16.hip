@@ -150,18 +150,25 @@ struct DwBfArgs {
 constexpr int DWB_SEG = 16;
 
 struct Row8 { float l[8], c[8], r[8]; };
+// one input row's three 16-byte column vectors as loaded (packed bf16) + which of them lie inside the image: the loads are issued
+// a whole output row AHEAD of their use (round 4), the zero-select and the unpacking happen when the row enters the window
+struct Raw3 { u32x4 l, c, r; bool lok, hok, rok; };
 
-__device__ __forceinline__ void dwb_load_row(const DwBfArgs& a, int b, int hi, int wi, int c0, Row8& o) {
-  const bool hok = hi >= 0 && hi < a.H;
+__device__ __forceinline__ Raw3 dwb_issue_row(const DwBfArgs& a, int b, int hi, int wi, int c0) {
+  Raw3 o;
+  o.hok = hi >= 0 && hi < a.H;
   const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi);
   const bf16_t* rowp = a.x + ((int64_t)b * a.H + hic) * a.W * a.C + c0;
-  const bool lok = hok && wi - 1 >= 0, rok = hok && wi + 1 < a.W;
+  o.lok = o.hok && wi - 1 >= 0; o.rok = o.hok && wi + 1 < a.W;
   const int wl = wi - 1 < 0 ? 0 : wi - 1, wr = wi + 1 >= a.W ? a.W - 1 : wi + 1;
+  o.l = ld16(rowp + (int64_t)wl * a.C); o.c = ld16(rowp + (int64_t)wi * a.C); o.r = ld16(rowp + (int64_t)wr * a.C);
+  return o;
+}
+__device__ __forceinline__ void dwb_unpack_row(const Raw3& q, Row8& o) {
   const u32x4 z = {0u, 0u, 0u, 0u};
-  const u32x4 l = ld16(rowp + (int64_t)wl * a.C), c = ld16(rowp + (int64_t)wi * a.C), r = ld16(rowp + (int64_t)wr * a.C);
-  unpack8(lok ? l : z, o.l);
-  unpack8(hok ? c : z, o.c);
-  unpack8(rok ? r : z, o.r);
+  unpack8(q.lok ? q.l : z, o.l);
+  unpack8(q.hok ? q.c : z, o.c);
+  unpack8(q.rok ? q.r : z, o.r);
 }
 
 template <int STRIDE>
@@ -189,12 +196,24 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(DwBfArgs a) {
     const int wo = (int)(it % a.Wo), sg = (int)((it / a.Wo) % nseg), b = (int)(it / ((int64_t)a.Wo * nseg));
     const int h0 = sg * DWB_SEG, h1 = h0 + DWB_SEG < a.Ho ? h0 + DWB_SEG : a.Ho;
     const int wi = wo * STRIDE;
+    // window rows of output row ho: ho*S - 1, ho*S, ho*S + 1.  Stride 1 slides by one input row per output row, stride 2 by two;
+    // the NEW rows of output row ho + 1 are in flight (qa, qb) while row ho is computed and stored.
     Row8 r0, r1, r2;
-    dwb_load_row(a, b, h0 * STRIDE - 1, wi, c0, r0);
-    if (STRIDE == 1) dwb_load_row(a, b, h0, wi, c0, r1);
+    {
+      const Raw3 t0 = dwb_issue_row(a, b, h0 * STRIDE - 1, wi, c0);
+      dwb_unpack_row(t0, r0);
+      if (STRIDE == 1) { const Raw3 t1 = dwb_issue_row(a, b, h0, wi, c0); dwb_unpack_row(t1, r1); }
+    }
+    Raw3 qa = dwb_issue_row(a, b, STRIDE == 1 ? h0 + 1 : 2 * h0, wi, c0);                    // stride 1: row ho + 1; stride 2: row 2 ho
+    Raw3 qb = STRIDE == 2 ? dwb_issue_row(a, b, 2 * h0 + 1, wi, c0) : qa;                      // stride 2: row 2 ho + 1
     for (int ho = h0; ho < h1; ++ho) {
-      if (STRIDE == 2) dwb_load_row(a, b, 2 * ho, wi, c0, r1);
-      dwb_load_row(a, b, ho * STRIDE + 1, wi, c0, r2);
+      const Raw3 ca = qa, cb = qb;
+      // next output row's new input rows: issued before this row's arithmetic and store (a load issued after a store could not be
+      // waited for without waiting for the store: in-order vmcnt); rows beyond the image are clamped and zero-selected
+      qa = dwb_issue_row(a, b, STRIDE == 1 ? ho + 2 : 2 * ho + 2, wi, c0);
+      if (STRIDE == 2) qb = dwb_issue_row(a, b, 2 * ho + 3, wi, c0);
+      if (STRIDE == 1) dwb_unpack_row(ca, r2);
+      else { dwb_unpack_row(ca, r1); dwb_unpack_row(cb, r2); }
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       fma_row(acc, r0, 0);
       fma_row(acc, r1, 1);
@@ -297,6 +316,7 @@ __global__ __launch_bounds__(64 * BW, 2) void pw_gemm_bf16_kernel(GemmBfArgs g) 
     return pack8(v);
   };
 
+  u32x4 cur[CH];
   for (int64_t s = wid; s < nslab; s += wtot) {
     const int64_t m0 = s * 32;
     int64_t gm = m0 + r;
@@ -308,13 +328,23 @@ __global__ __launch_bounds__(64 * BW, 2) void pw_gemm_bf16_kernel(GemmBfArgs g) 
     for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-    // k-loop in chunks of CH k-steps: the next chunk's fragments are requested before the current chunk is multiplied
-    u32x4 cur[CH], nxt[CH];
+    // k-loop in chunks of CH k-steps: the next chunk's fragments are requested before the current chunk is multiplied; round 4:
+    // the LAST chunk of a slab requests the first chunk of the wave's NEXT slab (it used to be loaded at the top of that slab
+    // and used at once: one exposed HBM latency per slab, covered only by the partner wave of the SIMD)
+    int64_t gmn = (s + wtot) * 32 + r;
+    gmn = gmn < M ? gmn : M - 1;
+    u32x4 nxt[CH];
+    if (s == wid) {
 #pragma unroll
-    for (int i = 0; i < CH; ++i) cur[i] = (AIN != 3 && i < NU) ? load_frag(gm, i) : u32x4{0u, 0u, 0u, 0u};
+      for (int i = 0; i < CH; ++i) cur[i] = (AIN != 3 && i < NU) ? load_frag(gm, i) : u32x4{0u, 0u, 0u, 0u};
+    }
     for (int u0 = 0; u0 < NU; u0 += CH) {
+      const bool lastc = u0 + CH >= NU;
 #pragma unroll
-      for (int i = 0; i < CH; ++i) nxt[i] = (AIN != 3 && u0 + CH + i < NU) ? load_frag(gm, u0 + CH + i) : u32x4{0u, 0u, 0u, 0u};
+      for (int i = 0; i < CH; ++i)
+        nxt[i] = AIN == 3 ? u32x4{0u, 0u, 0u, 0u}
+                          : (lastc ? (i < NU ? load_frag(gmn, i) : u32x4{0u, 0u, 0u, 0u})
+                                   : (u0 + CH + i < NU ? load_frag(gm, u0 + CH + i) : u32x4{0u, 0u, 0u, 0u}));
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
         const int u = u0 + i;

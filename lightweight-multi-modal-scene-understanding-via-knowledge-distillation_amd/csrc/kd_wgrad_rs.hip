@@ -248,7 +248,9 @@ int rs_mode() {
 }
 
 bool rs_wide12() {
-  static const bool on = [] { const char* e = getenv("KD_WGRAD_RS_WIDE12"); return e && e[0] == '1'; }();
+  // twelve k-blocks per matrix wave for 128 x 384 (one slice) and 128 x 768 (two slices): the narrow operand is converted once / twice
+  // instead of twice / four times.  Measured at 256 frames: 220 -> 192 us and 418 -> 364 us (profiles/r04_wgrad_rs_ab.txt); =0 restores six.
+  static const bool on = [] { const char* e = getenv("KD_WGRAD_RS_WIDE12"); return !(e && e[0] == '0'); }();
   return on;
 }
 
@@ -273,7 +275,7 @@ bool rs_plan(int N, int K, RsPlan& p, bool any = false) {
       {8, 4, 2, 4, 4, 1, 1},    // 768 x 128  stage-5 expand (3 column slices of 256)
       {2, 6, 1, 3, 2, 2, 2},    // 64 x 192 stage-2 project; 64 x 384 stage-3 project (2 slices)
       {4, 6, 1, 6, 4, 1, 2},    // 128 x 384 stage-4 project (2 slices); 128 x 768 stage-5 project (4 slices)
-      {4, 12, 1, 12, 4, 1, 1},  // the same two layers with twelve k-blocks per wave (KD_WGRAD_RS_WIDE12=1): D converted once / twice instead of twice / four times
+      {4, 12, 1, 12, 4, 1, 1},  // 128 x 384 stage-4 project (one slice); 128 x 768 stage-5 project (2 slices): twelve k-blocks per wave (default)
       {4, 4, 2, 2, 2, 2, 2},    // 128 x 128  FPN laterals / post, fusion projections
       {4, 2, 2, 1, 2, 2, 2},    // 128 x 64   FPN lateral of stage 3
       {2, 4, 1, 2, 2, 2, 2},    // 64 x 128   head block 0
