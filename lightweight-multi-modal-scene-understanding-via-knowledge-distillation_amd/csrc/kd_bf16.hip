@@ -316,7 +316,6 @@ __global__ __launch_bounds__(64 * BW, 2) void pw_gemm_bf16_kernel(GemmBfArgs g) 
     return pack8(v);
   };
 
-  u32x4 cur[CH];
   for (int64_t s = wid; s < nslab; s += wtot) {
     const int64_t m0 = s * 32;
     int64_t gm = m0 + r;
@@ -328,23 +327,15 @@ __global__ __launch_bounds__(64 * BW, 2) void pw_gemm_bf16_kernel(GemmBfArgs g) 
     for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-    // k-loop in chunks of CH k-steps: the next chunk's fragments are requested before the current chunk is multiplied; round 4:
-    // the LAST chunk of a slab requests the first chunk of the wave's NEXT slab (it used to be loaded at the top of that slab
-    // and used at once: one exposed HBM latency per slab, covered only by the partner wave of the SIMD)
-    int64_t gmn = (s + wtot) * 32 + r;
-    gmn = gmn < M ? gmn : M - 1;
-    u32x4 nxt[CH];
-    if (s == wid) {
+    // k-loop in chunks of CH k-steps: the next chunk's fragments are requested before the current chunk is multiplied
+    // (round 4: also requesting the NEXT slab's first chunk during the last chunk of this one -- no exposed latency at the top of a
+    // slab -- measured 11 % SLOWER over the 18 launches of the forward, 3.70 -> 4.11 ms: not kept)
+    u32x4 cur[CH], nxt[CH];
 #pragma unroll
-      for (int i = 0; i < CH; ++i) cur[i] = (AIN != 3 && i < NU) ? load_frag(gm, i) : u32x4{0u, 0u, 0u, 0u};
-    }
+    for (int i = 0; i < CH; ++i) cur[i] = (AIN != 3 && i < NU) ? load_frag(gm, i) : u32x4{0u, 0u, 0u, 0u};
     for (int u0 = 0; u0 < NU; u0 += CH) {
-      const bool lastc = u0 + CH >= NU;
 #pragma unroll
-      for (int i = 0; i < CH; ++i)
-        nxt[i] = AIN == 3 ? u32x4{0u, 0u, 0u, 0u}
-                          : (lastc ? (i < NU ? load_frag(gmn, i) : u32x4{0u, 0u, 0u, 0u})
-                                   : (u0 + CH + i < NU ? load_frag(gm, u0 + CH + i) : u32x4{0u, 0u, 0u, 0u}));
+      for (int i = 0; i < CH; ++i) nxt[i] = (AIN != 3 && u0 + CH + i < NU) ? load_frag(gm, u0 + CH + i) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
         const int u = u0 + i;
