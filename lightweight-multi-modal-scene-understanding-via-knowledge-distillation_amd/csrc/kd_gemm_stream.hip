@@ -14,7 +14,6 @@ using namespace kd_stream;
 // data-gradient instantiations (kd_gemm_stream_bwd0.hip / _bwd2.hip): 1 launched, 0 no such instance
 int kd_stream_bwd0_dispatch(const GemmArgs& g, int kb, int nb, dim3 grid, hipStream_t st);             // PRO2, EPI0
 int kd_stream_bwd2_dispatch(const GemmArgs& g, int kb, int nb, int pro, int epi, dim3 grid, hipStream_t st);   // PRO2/4, EPI2/3
-int kd_stream_wide_dispatch(const GemmArgs& g, int kb, int nb, int pro, int epi, dim3 grid, hipStream_t st);   // K = 192 -> N = 32 data gradient (kd_gemm_stream_wide.hip)
 
 namespace {
 
@@ -43,20 +42,17 @@ bool stream_cfg(int K, int N, int pro, int epi, bool add, StreamCfg& c) {
   const bool bwd = (pro == 2 && (epi == 0 || epi == 2)) || (pro == 4 && epi == 2 && kb == 4 && nbt == 4);
   if (!fwd && !bwd) return false;
   if (bwd && mode == 3) return false;                 // mode 3: forward shapes only (A/B of the data-gradient kernels)
-  // K = 32, 64, 128; round 4: the K = 192 -> N = 32 data gradient (kd_gemm_stream_wide.hip: the one wider reduction that wins;
-  // KD_GEMM_STREAM_WIDE=0 leaves it to the tiled kernel)
-  const bool wide = kb == 6;
-  if (wide) {
-    static const bool wide_on = [] { const char* e = getenv("KD_GEMM_STREAM_WIDE"); return !(e && e[0] == '0'); }();
-    if (!wide_on || mode < 2 || pro != 2 || nbt != 1 || (epi == 2 && add)) return false;
-  } else if (!(kb == 1 || kb == 2 || kb == 4)) return false;
+  // K = 32, 64, 128.  Round 4 re-measured K = 192 / 256 / 384 in the two-register-set form (profiles/r04_stream_wide_k.txt): in isolation only
+  // the K = 192 -> N = 32 data gradient won (1444 -> 1314 us), and inside the KD step not even that (1163 us tiled, 1173-1279 us streaming):
+  // every K >= 192 reduction stays on the tiled kernel.
+  if (!(kb == 1 || kb == 2 || kb == 4)) return false;
   if (pro == 3 && kb != 2) return false;
   // widest column tile (in 32-column blocks) that divides N and whose three W planes + tables fit the LDS
   int nb = 0;
-  for (int cand = wide ? 2 : 4; cand >= 1; cand >>= 1)
+  for (int cand = 4; cand >= 1; cand >>= 1)
     if (nbt % cand == 0 && stream_lds_bytes(K, 32 * cand, pro) <= LDS_MAX) { nb = cand; break; }
   if (nb == 0) return false;
-  if (!wide && pro == 2 && epi == 2) {
+  if (pro == 2 && epi == 2) {
     const int sig = kb * 100 + nb * 10 + (add ? 1 : 0);
     if (sig == 120 || sig == 141 || sig == 211 || sig == 220 || sig == 241 || sig == 411 || sig == 420 || sig == 441) return false;
   }
@@ -112,8 +108,7 @@ int kd_gemm_stream_launch(GemmArgs& g, int pro, int epi, hipStream_t st) {
   if (!stream_cfg(g.K, g.N, pro, epi, g.addend != nullptr, c)) return 0;
   const dim3 grid(stream_grid(g.M, c.ntiles), c.ntiles);
   int rc = 0;
-  if (c.kb == 6) rc = kd_stream_wide_dispatch(g, c.kb, c.nb, pro, epi, grid, st);
-  else if (pro == 2 && epi == 0) rc = kd_stream_bwd0_dispatch(g, c.kb, c.nb, grid, st);
+  if (pro == 2 && epi == 0) rc = kd_stream_bwd0_dispatch(g, c.kb, c.nb, grid, st);
   else if (pro == 2 || pro == 4) rc = kd_stream_bwd2_dispatch(g, c.kb, c.nb, pro, epi, grid, st);
   else {
     // (K / 32, chunk / 32, N tile / 32, two register sets).  Measured per shape (tools/bench_stream, M = 32 frames): K = 128 and

@@ -66,8 +66,27 @@ __device__ __forceinline__ int sw_key(int n) {
   else { static_assert(CPR == 4, "K must be 32 or a multiple of 64"); return (n >> 2) & 3; }
 }
 
+// KD_STREAM_TSTORE (default 1): a finished 32 x 32 accumulator block leaves through a wave-private LDS tile (rows padded to 36 floats;
+// LDS is in-order per wave: no barrier) as four 16-byte-per-lane stores of eight whole 128-byte row segments each, instead of
+// sixteen dword stores (two 128-byte segments each).  =0 builds the dword form (A/B: profiles/r04_stream_tstore_ab.txt).
+#ifndef KD_STREAM_TSTORE
+#define KD_STREAM_TSTORE 1
+#endif
+constexpr bool STREAM_TSTORE = KD_STREAM_TSTORE != 0;
+// Which instances use it, from the in-step per-launch A/B (same box, tools/r4_ab_stream.sh, profiles/r04_stream_tstore_ab.txt): the
+// 128-wide column tiles gain 2-6 % (128 -> 128: 236 -> 224 us, LiDAR layer 2: 4581 -> 4428 us) and so do the 32 -> 192 expand launches
+// (three 64-wide tiles: 787 -> 748 us); the narrow outputs (N = 32 / 64 in one tile) and the layer-0-recompute launch lose 2-8 %
+// (their dword stores already write whole 128-byte segments; the transposition only adds LDS traffic); the mask epilogue (EPI 2)
+// sits at the 256-register limit and spills with the tile.
+constexpr bool stream_tstore(int kb, int nb, int pro, int epi) {
+  return STREAM_TSTORE && epi != 2 && pro != 3 && (nb == 4 || (nb == 2 && kb == 1));
+}
+constexpr int STREAM_TR = 32 * 36;                                      // floats per wave-private transposition tile
+
 constexpr int stream_nco(int pro) { return pro == 1 ? 2 : (pro == 3 ? 7 : ((pro == 2 || pro == 4) ? 5 : 0)); }
-constexpr size_t stream_lds_bytes(int K, int N, int pro) { return (size_t)3 * N * K * 2 + (size_t)(stream_nco(pro) > 0 ? stream_nco(pro) : 1) * K * 4; }
+constexpr size_t stream_lds_bytes(int K, int N, int pro) {
+  return (size_t)3 * N * K * 2 + (size_t)(stream_nco(pro) > 0 ? stream_nco(pro) : 1) * K * 4 + (STREAM_TSTORE ? (size_t)8 * STREAM_TR * 4 : 0);
+}
 
 // KB = K / 32, KC = chunk width / 32 (divides KB), NB = column-tile width / 32.
 // DB: two register sets per streamed tensor -- the loads of chunk c + 1 are issued BEFORE the k-loop of chunk c.
@@ -84,6 +103,7 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* Wh = reinterpret_cast<unsigned short*>(smem_raw);      // [3][N][K] bf16, swizzled
   float* Co = reinterpret_cast<float*>(smem_raw + 3 * WPL * 2);         // [NCO][K] coefficient tables
+  float* trt = Co + (NCO > 0 ? NCO : 1) * K + (threadIdx.x >> 6) * STREAM_TR;   // this wave's transposition tile (STREAM_TSTORE)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.y * N;                                         // column tile (N_total > N: several tiles)
@@ -315,12 +335,27 @@ __global__ __launch_bounds__(64 * SW, 2) void pw_stream_kernel(GemmArgs g) {
             v *= kd_act_mask(kd_affine(x, esc[j], esh[j]), g.epi_act);
             if (rok) { s1[j] += v; s2[j] = fmaf(v, (x - emean[j]) * einv[j], s2[j]); }
           }
-          float* dst = cbase + (int64_t)rbase * g.ldc + c_lane;
-          if (FULL) {
-            if (g.nt_store) __builtin_nontemporal_store(v, dst); else *dst = v;
-          } else if (rok) {
-            *dst = v;
+          if constexpr (stream_tstore(KB, NB, PRO, EPI)) {
+            trt[(rbase + 4 * h) * 36 + r] = v;
+          } else {
+            float* dst = cbase + (int64_t)rbase * g.ldc + c_lane;
+            if (FULL) {
+              if (g.nt_store) __builtin_nontemporal_store(v, dst); else *dst = v;
+            } else if (rok) {
+              *dst = v;
+            }
           }
+        }
+      }
+      if constexpr (stream_tstore(KB, NB, PRO, EPI)) {
+        // the block as rows: lane -> columns 4 (lane & 7) .. + 3 of rows (lane >> 3) + 8 p
+        const int tc4 = (lane & 7) * 4, tr0 = lane >> 3;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int rr = tr0 + 8 * p;
+          const float4 v = kd_ld4(trt + rr * 36 + tc4);
+          float* dst = cbase + (int64_t)rr * g.ldc + tc4;
+          if (FULL || m0 + rr < M) { if (g.nt_store) kd_st4_nt(dst, v); else kd_st4(dst, v); }
         }
       }
     }
