@@ -50,6 +50,14 @@ def main():
                         # the test's own criterion, with margin: a clean seed sits at <= 1e-5 / 5e-5 everywhere
                         ok = ok and med(gpu) <= 1e-5 and gpu[-1] <= 4e-5
                         cols.append(f"{arith}/s{mode} med {med(gpu):.1e} max {gpu[-1]:.1e}")
+                    if arith == "split":            # round 4: the weight-gradient forms (tiled everywhere / every role-specialised instance)
+                        lib.kd_set_gemm_stream(2)
+                        for wg in (0, 2):
+                            prev_wg = lib.kd_set_wgrad_rs(wg)
+                            gpu = fp64_rel_errors(g64, fp64_gpu_grads(fusion, obj, seed))
+                            lib.kd_set_wgrad_rs(prev_wg)
+                            ok = ok and med(gpu) <= 1e-5 and gpu[-1] <= 4e-5
+                            cols.append(f"split/wgrad{wg} med {med(gpu):.1e} max {gpu[-1]:.1e}")
                 line = f"{key} seed {seed}: " + " | ".join(cols) + (" | CLEAN" if ok else " | flip")
                 print(line, flush=True)
                 scan.append(line)

@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
 """tools/diag_fp64_seeds.py OUT.json -> tests/golden/fp64_clean_seeds.json (the seed table the fp64 gradient test reads) and
-profiles/r03_fp64_seed_scan.txt (the scan lines).  usage: fp64_seed_table.py OUT.json SCAN.log"""
+profiles/r04_fp64_seed_scan.txt (the scan lines).  usage: fp64_seed_table.py OUT.json SCAN.log"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.load(open(sys.argv[1]))
-tab = {"note": "input seeds whose batch keeps every evaluation (CPU fp32 oracle, GPU split / fp32 arithmetic x streaming mode 0/1/2) clear of "
-               "activation kinks; tools/diag_fp64_seeds.py on an MI355X, scan lines in profiles/r03_fp64_seed_scan.txt; the test takes the "
-               "first three seeds of a case and needs two of them to pass",
+tab = {"note": "input seeds whose batch keeps every evaluation (CPU fp32 oracle, GPU split / fp32 arithmetic x streaming mode 0/1/2, weight-gradient form 0/2) clear of "
+               "activation kinks; tools/diag_fp64_seeds.py on an MI355X, scan lines in profiles/r04_fp64_seed_scan.txt; the test takes the "
+               "first three seeds of a case and needs ALL of them to pass (round 4)",
        "clean": d["clean"]}
 json.dump(tab, open(os.path.join(ROOT, "tests", "golden", "fp64_clean_seeds.json"), "w"), indent=1)
 lines = [l for l in open(sys.argv[2]).read().splitlines() if " seed " in l and ("CLEAN" in l or "flip" in l)]
-head = ("tools/diag_fp64_seeds.py OUT 1 20 3 on an MI355X (round 3, final kernels): per (objective/student fusion, input seed), per-tensor relative L2\n"
+head = ("tools/diag_fp64_seeds.py OUT 1 20 3 on an MI355X (round 4, final kernels; split/wgrad0 / wgrad2 = weight-gradient form tiled / role-specialised): per (objective/student fusion, input seed), per-tensor relative L2\n"
         "distance of the gradients to the float64 oracle: median / max over ~90 tensors.  cpu32 = the fp32 CPU oracle; split|fp32 = GEMM arithmetic;\n"
         "s0/s1/s2 = streaming mode.  A 'flip' line is a batch with a pre-activation within fp32 rounding of a ReLU kink (1e-2-class error in some\n"
         "evaluations, 1e-6 in others).\n\n")
-open(os.path.join(ROOT, "profiles", "r03_fp64_seed_scan.txt"), "w").write(head + "\n".join(lines) + "\n")
+open(os.path.join(ROOT, "profiles", "r04_fp64_seed_scan.txt"), "w").write(head + "\n".join(lines) + "\n")
 print({k: v for k, v in d["clean"].items()})
