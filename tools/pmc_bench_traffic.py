@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def family(k):
     if "pw_gemm_kernel" in k or "pw_stream_kernel" in k:
         return "pw_gemm+pw_stream"
-    if "pw_wgrad_kernel" in k:
+    if "pw_wgrad_kernel" in k or "pw_wgrad_rs_kernel" in k:
         return "pw_wgrad_kernel"
     if "lidar_l2_bwd_kernel" in k or "lidar_l1_bwd_kernel" in k:
         return "lidar_bwd"

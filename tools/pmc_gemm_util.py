@@ -9,7 +9,7 @@ def load(d):
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for r in csv.DictReader(open((glob.glob(d + "/*/*_counter_collection.csv") + glob.glob(d + "/*_counter_collection.csv"))[0])):
         n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("kd_stream::", "").replace("void ", "")
-        if not any(t in n for t in ("pw_gemm_kernel", "pw_wgrad_kernel", "pw_stream_kernel", "lidar_l", "lidar_mlp", "pw_gemm_bf16", "dw_")):
+        if not any(t in n for t in ("pw_gemm_kernel", "pw_wgrad_kernel", "pw_wgrad_rs_kernel", "pw_stream_kernel", "lidar_l", "lidar_mlp", "pw_gemm_bf16", "dw_")):
             continue
         k = (n.split("(")[0], int(r["Grid_Size"]) // int(r["Workgroup_Size"]))
         a = agg[k][r["Counter_Name"]]

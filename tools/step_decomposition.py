@@ -5,7 +5,7 @@ import collections, csv, sys
 
 FAMILIES = [
     ("1x1 conv / point MLP: forward + data gradient (pw_stream / pw_gemm)", ("pw_stream_kernel", "pw_gemm_kernel")),
-    ("1x1 conv / point MLP: weight gradient (pw_wgrad + slab reduce)", ("pw_wgrad_kernel", "wgrad_reduce")),
+    ("1x1 conv / point MLP: weight gradient (pw_wgrad / pw_wgrad_rs + slab reduce)", ("pw_wgrad_kernel", "pw_wgrad_rs_kernel", "wgrad_reduce")),
     ("depthwise 3x3 forward / backward (dw_*)", ("dw_fwd", "dw_bwd")),
     ("fused inference tails (dw_pw_infer)", ("dw_pw_infer",)),
     ("LiDAR: point sort, layer-0 passes, scatter-max forward / backward (seg_*, lidar_*, sort)", ("seg_", "lidar_", "sort_", "scan_", "stable_", "rank_", "hist", "scatter", "gather_sorted", "bev_")),
