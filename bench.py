@@ -660,12 +660,20 @@ def main():
         # eager and as one replayed hipGraph).  Bounded: 5 timed steps per student at the benchmarked batch, 20 at B=4.
         torch.cuda.empty_cache()
         ns = max(3, min(args.steps, 5))
+
+        def guarded(*a, **k):
+            # a side line that fails (e.g. out of memory beside the headline models on a smaller card) must not cost the headline line
+            try:
+                return side_rate(*a, **k)
+            except Exception as e:                                 # noqa: BLE001 -- reported in the JSON, never swallowed silently
+                torch.cuda.empty_cache()
+                return {"error": f"{type(e).__name__}: {e}"[:300]}
         out["ablation"] = {"what": f"KD step frames/s per student fusion, {args.teacher_fusion} teacher, B={args.batch}, same box, {ns} timed steps each (configs[4])"}
         for sf in ("concat", "minimal", "weighted"):
-            out["ablation"][sf] = side_rate(args, dev, sf, args.batch, ns)
+            out["ablation"][sf] = guarded(args, dev, sf, args.batch, ns)
         out["small_batch"] = {"what": f"the reference's batch (B=4), {args.student_fusion} student, N={args.points} points: eager launches vs the whole step as one replayed hipGraph, 20 timed steps each",
-                              "B4_eager": side_rate(args, dev, args.student_fusion, 4, 20),
-                              "B4_hipgraph": side_rate(args, dev, args.student_fusion, 4, 20, graph=True)}
+                              "B4_eager": guarded(args, dev, args.student_fusion, 4, 20),
+                              "B4_hipgraph": guarded(args, dev, args.student_fusion, 4, 20, graph=True)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(teacher, student, args.points, args.image, args.grid, args.teacher_fusion, args.student_fusion)
     if rank == 0:
