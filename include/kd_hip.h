@@ -96,6 +96,9 @@ int kd_copy_segments(const float* s0, float* d0, int64_t n0, const float* s1, fl
 int64_t kd_stem_stat_rows(int64_t npix_out);
 int kd_stem_conv_fwd(const float* x_nchw, const float* w, float* y_nhwc, float* partial, int B, int Cin, int H,
                      int W, int Cout, void* stream);
+/* inference (eval mode, no autograd): y = act(conv(x) * sc + sh) in one kernel, Cin == 3; the bits of kd_stem_conv_fwd + kd_bn_act_apply */
+int kd_stem_conv_fwd_infer(const float* x_nchw, const float* w, const float* sc, const float* sh, int act, float* y_nhwc,
+                           int B, int Cin, int H, int W, int Cout, void* stream);
 /* im2col (K padded to Kp, zeros) so that the stem weight gradient is kd_pwconv_wgrad with K = Kp. */
 int kd_stem_im2col(const float* x_nchw, float* col, int B, int Cin, int H, int W, int Kp, void* stream);
 

@@ -90,14 +90,21 @@ __global__ __launch_bounds__(256) void bilinear_sum_fwd_kernel(Bl3Args a) {
         bl_src(wo, a.Wi[t], a.sww[t], w0, w1, lw0, lw1);
         const float* base = a.in[t] + (int64_t)b * a.Hi[t] * a.Wi[t] * a.C + c0;
         const float4 v00 = kd_affine_act4(kd_ld4(base + ((int64_t)h0 * a.Wi[t] + w0) * a.C), sc[t], sh[t], a.act[t]);
-        const float4 v01 = kd_affine_act4(kd_ld4(base + ((int64_t)h0 * a.Wi[t] + w1) * a.C), sc[t], sh[t], a.act[t]);
-        const float4 v10 = kd_affine_act4(kd_ld4(base + ((int64_t)h1 * a.Wi[t] + w0) * a.C), sc[t], sh[t], a.act[t]);
-        const float4 v11 = kd_affine_act4(kd_ld4(base + ((int64_t)h1 * a.Wi[t] + w1) * a.C), sc[t], sh[t], a.act[t]);
         float4 v;
-        v.x = lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x);
-        v.y = lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y);
-        v.z = lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z);
-        v.w = lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
+        if (a.Hi[t] == a.Ho && a.Wi[t] == a.Wo && a.act[t] != KD_ACT_NONE) {
+          // a lateral already at the output size (weights 1, 0, 0, 0): one load instead of four.  The general expression below gives
+          // 1 * (1 * v00 + 0 * v01) + 0 * (...) = v00 + 0 for finite values, which equals v00 bit for bit unless v00 is -0.0 --
+          // and an activated (ReLU / ReLU6) value never is.  (wave-uniform branch)
+          v = make_float4(v00.x + 0.f, v00.y + 0.f, v00.z + 0.f, v00.w + 0.f);
+        } else {
+          const float4 v01 = kd_affine_act4(kd_ld4(base + ((int64_t)h0 * a.Wi[t] + w1) * a.C), sc[t], sh[t], a.act[t]);
+          const float4 v10 = kd_affine_act4(kd_ld4(base + ((int64_t)h1 * a.Wi[t] + w0) * a.C), sc[t], sh[t], a.act[t]);
+          const float4 v11 = kd_affine_act4(kd_ld4(base + ((int64_t)h1 * a.Wi[t] + w1) * a.C), sc[t], sh[t], a.act[t]);
+          v.x = lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x);
+          v.y = lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y);
+          v.z = lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z);
+          v.w = lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
+        }
         if (t == 0) r = v; else { r.x = v.x + r.x; r.y = v.y + r.y; r.z = v.z + r.z; r.w = v.w + r.w; }
       }
     }
@@ -134,6 +141,10 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs a) {
       olo = olo < 0 ? 0 : olo; plo = plo < 0 ? 0 : plo;
       ohi = ohi > a.Ho - 1 ? a.Ho - 1 : ohi; phi = phi > a.Wo - 1 ? a.Wo - 1 : phi;
       float4 acc = kd_zero4();
+      if (a.Hi == a.Ho && a.Wi == a.Wo) {              // same size: the adjoint is the identity (fma(1, d, 0) = d: the bits of the general loop)
+        acc = kd_ld4(a.dout + p * a.C + c0);
+        olo = 1; ohi = 0;                               // (skips the gather loops below)
+      }
       for (int oh = olo; oh <= ohi; ++oh) {
         const float wh = bl_weight(oh, hi, a.Hi, a.sh_);
         if (wh == 0.f) continue;

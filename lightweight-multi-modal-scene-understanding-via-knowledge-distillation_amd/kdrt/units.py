@@ -480,6 +480,22 @@ def chain_backward(recs: Sequence[_Rec], g, need_input_grad=True, first_addend=N
     return all_grads, g
 
 
+_STEM_INFER = os.environ.get("KD_STEM_INFER", "1") != "0"       # 0: stem conv and its BatchNorm + activation as two passes also in inference
+
+
+def stem_infer(spec: UnitSpec, img):
+    """Inference (eval, no autograd) stem: 3x3/s2 conv + BatchNorm + ReLU6 in ONE kernel (camera_encoder.py:63-67)."""
+    img = img if img.is_contiguous() else img.contiguous()
+    B, Cin, H, W = img.shape
+    w = spec.conv.weight
+    Cout = w.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    bnc = _coeffs(spec, None, 0, Cout, B * Ho * Wo, False, None, img.device)
+    y = torch.empty(B * Ho * Wo, Cout, device=img.device, dtype=torch.float32)
+    lib.call("kd_stem_conv_fwd_infer", P(img), P(w), P(bnc.scale), P(bnc.shift), spec.act, P(y), B, Cin, H, W, Cout, stream())
+    return y, (B, Ho, Wo)
+
+
 def _params_of(units: Sequence[UnitSpec]) -> List[torch.Tensor]:
     out = []
     for u in units:
@@ -505,6 +521,9 @@ class ChainFn(torch.autograd.Function):
             cur = Operand(xm, geom)
         if inference_tail_ok(units, infer):
             out, geom = infer_tail(units, cur, res=xm if residual else None)
+            return ops.nchw_from_matrix(out, geom)
+        if infer and _STEM_INFER and len(units) == 1 and units[0].kind == "stem" and not residual and x.shape[1] == 3:
+            out, geom = stem_infer(units[0], x)          # conv + eval BatchNorm + activation in one kernel (same bits as the two passes)
             return ops.nchw_from_matrix(out, geom)
         for u in units:
             cur, rec = unit_forward(u, cur, training)

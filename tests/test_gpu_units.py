@@ -556,3 +556,23 @@ def test_chain_pairs_match_separate_chains(monkeypatch):
     for n in g0:
         scale = max(g0[n].abs().max().item(), 1e-2 * gmax)
         assert (g1[n] - g0[n]).abs().max().item() <= 2e-5 * scale, (n, (g1[n] - g0[n]).abs().max().item(), scale)
+
+
+def test_stem_inference_kernel_same_bits_as_two_passes(monkeypatch):
+    """Inference (eval, no autograd): the stem's conv + BatchNorm + ReLU6 run as ONE kernel (kd_stem_conv_fwd_infer); with
+    KD_STEM_INFER=0 as conv + kd_bn_act_apply.  Same operations in the same order: every multiscale map has the same bits."""
+    from kdrt import units
+    from src.models.camera_encoder import TwinLiteEncoder
+    torch.manual_seed(4)
+    x = torch.randn(3, 3, 70, 94, device="cuda")
+    enc = TwinLiteEncoder(return_multiscale=True)
+    _rand_state(enc, 23)
+    enc = enc.cuda().eval()
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(units, "_STEM_INFER", fused)
+        with torch.no_grad():
+            res[fused] = enc(x)
+    assert set(res[True]) == set(res[False]) == {"stage2", "stage3", "stage4", "stage5"}
+    for k in res[True]:
+        assert torch.equal(res[True][k].view(torch.int32), res[False][k].view(torch.int32)), k
