@@ -46,13 +46,22 @@ __global__ __launch_bounds__(256) void lidar_l0_fwd_kernel(L0Args a) {
   float4 s1 = kd_zero4(), s2 = kd_zero4();
   if (a.p_dev) { const int64_t pv = *a.p_dev; a.P = pv < a.P ? pv : a.P; }
   if (active) {
-    for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < a.P; p += (int64_t)gridDim.x * a.slots) {
-      const float4 pt = kd_ld4(a.pts + p * 4);
+    // Four points of this thread in flight (round 4): one dependent 16-byte load per ~30 VALU operations left the kernel 82 % of its
+    // wave cycles waiting (profiles/r03_gemm_pmc_utilisation.txt).  The sums still receive the points in the same order.
+    const int64_t stride = (int64_t)gridDim.x * a.slots;
+    auto one = [&](int64_t p, float4 pt) __attribute__((always_inline)) {
       const float4 v = kd_l0_raw4(pt, wr, bias);
       if (a.y) kd_st4(a.y + p * a.C + c0, v);          // y == NULL: statistics only, consumers recompute the layer
       s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
       s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+    };
+    int64_t p = (int64_t)blockIdx.x * a.slots + slot;
+    for (; p + 3 * stride < a.P; p += 4 * stride) {
+      const float4 q0 = kd_ld4(a.pts + p * 4), q1 = kd_ld4(a.pts + (p + stride) * 4), q2 = kd_ld4(a.pts + (p + 2 * stride) * 4),
+                   q3 = kd_ld4(a.pts + (p + 3 * stride) * 4);
+      one(p, q0); one(p + stride, q1); one(p + 2 * stride, q2); one(p + 3 * stride, q3);
     }
+    for (; p < a.P; p += stride) one(p, kd_ld4(a.pts + p * 4));
   }
   if (a.partial) {
     kd_st4(red + tid * 4, s1);
@@ -91,8 +100,9 @@ __global__ __launch_bounds__(256) void lidar_l0_bwd_kernel(L0BwdArgs a) {
       for (int j = 0; j < 4; ++j) wr[j] = kd_ld4(a.w + (c0 + j) * 4);
       if (a.b) bias = kd_ld4(a.b + c0);
     }
-    for (int64_t p = (int64_t)blockIdx.x * a.slots + slot; p < a.P; p += (int64_t)gridDim.x * a.slots) {
-      const float4 pt = kd_ld4(a.pts + p * 4);
+    const int64_t stride = (int64_t)gridDim.x * a.slots;
+    // (four points in flight, accumulated in the same order: see lidar_l0_fwd_kernel)
+    auto one = [&](int64_t p, float4 pt) __attribute__((always_inline)) {
       // D == NULL: the gradient-dependent part comes from kd_lidar_l1_dgrad's moments; this pass adds sum (be*y + ga) * pt
       const float4 d = a.D ? kd_ld4(a.D + p * a.C + c0) : kd_zero4();
       const float4 y = a.Y ? kd_ld4(a.Y + p * a.C + c0) : kd_l0_raw4(pt, wr, bias);
@@ -108,7 +118,14 @@ __global__ __launch_bounds__(256) void lidar_l0_bwd_kernel(L0BwdArgs a) {
         acc[i].z = fmaf(g.z, pv[i], acc[i].z); acc[i].w = fmaf(g.w, pv[i], acc[i].w);
       }
       acc[4].x += g.x; acc[4].y += g.y; acc[4].z += g.z; acc[4].w += g.w;
+    };
+    int64_t p = (int64_t)blockIdx.x * a.slots + slot;
+    for (; p + 3 * stride < a.P; p += 4 * stride) {
+      const float4 q0 = kd_ld4(a.pts + p * 4), q1 = kd_ld4(a.pts + (p + stride) * 4), q2 = kd_ld4(a.pts + (p + 2 * stride) * 4),
+                   q3 = kd_ld4(a.pts + (p + 3 * stride) * 4);
+      one(p, q0); one(p + stride, q1); one(p + 2 * stride, q2); one(p + 3 * stride, q3);
     }
+    for (; p < a.P; p += stride) one(p, kd_ld4(a.pts + p * 4));
   }
   for (int t = 0; t < 5; ++t) {
     __syncthreads();

@@ -410,3 +410,31 @@ def test_lidar_l1_fused_backward_against_the_two_kernels_and_fp64(M):
     from kdrt.lib import KDError
     with pytest.raises(KDError, match="statistics slab"):
         lib.call("kd_lidar_l1_bwd", *args, rows_f + 1, P(m1b), P(dWb), M, N1, K0, P(ws2), nb2, stream())
+
+
+@pytest.mark.parametrize("M,N,K", [(3000, 128, 256), (2049, 384, 64), (1777, 128, 768)])
+def test_role_specialised_wgrad_on_column_slices_of_wider_buffers(M, N, K):
+    """D / X / A as column slices of wider row-major buffers (row stride != width), as the fusion block hands its operands
+    over (both projections live in one [M, 256] buffer): the role-specialised kernel must honour ldd / ldx / lda."""
+    from kdrt import ops
+    if ops.get_gemm_arithmetic() != "split":
+        pytest.skip("the role-specialised weight gradient exists in the split arithmetic only")
+    g = torch.Generator().manual_seed(M + N + K)
+    Gb, Yb, Ab = torch.randn(M, N + 64, generator=g), torch.randn(M, 2 * N, generator=g), torch.randn(M, K + 32, generator=g)
+    G, Y, A = Gb[:, 32:32 + N], Yb[:, N:], Ab[:, 16:16 + K]
+    al, be, ga = (torch.randn(N, generator=g) * 0.5 for _ in range(3))
+    msc, msh = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
+    asc, ash = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
+    d = lambda t: t.double()
+    dy = d(al) * (d(G) * ((d(Y) * d(msc) + d(msh)) > 0).double()) + d(be) * d(Y) + d(ga)
+    want = dy.t() @ (d(A) * d(asc) + d(ash)).clamp_min(0)
+    c = lambda t: t.cuda()
+    Gd, Yd, Ad = c(Gb)[:, 32:32 + N], c(Yb)[:, N:], c(Ab)[:, 16:16 + K]
+    prev = ops.lib.kd_set_wgrad_rs(2)
+    try:
+        dW = torch.full((N, K), float("nan"), device="cuda")
+        ops.pw_wgrad(Gd, Ad, dW, M=M, N=N, K=K, X=Yd, d_mode=2, d_act=1, al=c(al), be=c(be), ga=c(ga), msc=c(msc), msh=c(msh),
+                     a_mode=1, a_act=1, asc=c(asc), ash=c(ash))
+    finally:
+        ops.lib.kd_set_wgrad_rs(prev)
+    _close(dW, want, "rs wgrad, strided operands")
