@@ -91,32 +91,107 @@ __device__ __forceinline__ void reduce_slab2(const float* partial, int rows, int
     for (int y = 0; y < FRL; ++y) { s1 += sm[y][0][threadIdx.x]; s2 += sm[y][1][threadIdx.x]; }
 }
 
-__global__ __launch_bounds__(FCW * FRL) void bn_finalize_train_kernel(const float* partial, int rows, int rstep, int C, int pstride, double count, const float* gamma,
-                                         const float* beta, float eps, float momentum, float* running_mean,
-                                         float* running_var, int64_t* nbt, float* mean, float* invstd, float* scale,
-                                         float* shift) {
+// Tall slabs (round 4).  The tiled GEMM leaves one statistics row per 128 matrix rows (8192 rows for a 1 M-row layer), the depthwise /
+// resize / reduce kernels one per workgroup (2048): with 16 channels per workgroup the form above puts a 64-channel layer's 4 MB slab
+// on FOUR compute units, each lane walking 128 rows eight at a time -- 33-58 us per BatchNorm where the short slabs of the streaming
+// GEMMs take 5-7 (rocprofv3 trace of the step, r04).  Here a workgroup owns FOUR channels (one 16-byte load per row and statistic) and
+// 256 row lanes: a 64-channel layer runs on 16 compute units and a lane walks 32 rows.  Lane y sums rows y, y + 256, ... in order
+// (eight rows in flight), in double; 64 threads then add 32 lanes each, in lane order, and 8 threads the eight group sums: fixed order.
+// Needs C, pstride multiples of 4 and a 16-byte-aligned slab; returns true in the four threads that hold a channel's sums.
+constexpr int TL = 256, TUN = 8;
+__device__ __forceinline__ bool reduce_slab2_tall(const float* partial, int rows, int rstep, int pstride, int c0, double& s1, double& s2,
+                                                  double (*sm)[8], double (*sg)[8]) {
+  const int y = threadIdx.x;
+  const int64_t rs = (int64_t)rstep * 2 * pstride;
+  const float* base = partial + c0;
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+  int r = y;
+  for (; r + (TUN - 1) * TL < rows; r += TUN * TL) {
+    float4 v[TUN], w[TUN];
+#pragma unroll
+    for (int u = 0; u < TUN; ++u) {
+      const float* q = base + (int64_t)(r + u * TL) * rs;
+      v[u] = kd_ld4(q);
+      w[u] = kd_ld4(q + pstride);
+    }
+#pragma unroll
+    for (int u = 0; u < TUN; ++u) {
+      a[0] += (double)v[u].x; a[1] += (double)v[u].y; a[2] += (double)v[u].z; a[3] += (double)v[u].w;
+      b[0] += (double)w[u].x; b[1] += (double)w[u].y; b[2] += (double)w[u].z; b[3] += (double)w[u].w;
+    }
+  }
+  {
+    float4 v[TUN], w[TUN];                            // the remainder, also fetched together
+#pragma unroll
+    for (int u = 0; u < TUN; ++u) {
+      const int rr = r + u * TL;
+      const bool ok = rr < rows;
+      const float* q = base + (int64_t)(ok ? rr : 0) * rs;
+      v[u] = kd_ld4(q);
+      w[u] = kd_ld4(q + pstride);
+      if (!ok) { v[u] = kd_zero4(); w[u] = kd_zero4(); }
+    }
+#pragma unroll
+    for (int u = 0; u < TUN; ++u) {
+      a[0] += (double)v[u].x; a[1] += (double)v[u].y; a[2] += (double)v[u].z; a[3] += (double)v[u].w;
+      b[0] += (double)w[u].x; b[1] += (double)w[u].y; b[2] += (double)w[u].z; b[3] += (double)w[u].w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { sm[y][i] = a[i]; sm[y][4 + i] = b[i]; }
+  __syncthreads();
+  if (y < 64) {                                       // thread (group = y >> 3, slot = y & 7): lanes 32 group .. 32 group + 31 of one slot
+    const int gq = y >> 3, slot = y & 7;
+    double t = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) t += sm[32 * gq + k][slot];
+    sg[gq][slot] = t;
+  }
+  __syncthreads();
+  s1 = s2 = 0.0;
+  if (y >= 4) return false;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1 += sg[k][y]; s2 += sg[k][4 + y]; }
+  return true;
+}
+
+struct TrainTail {
+  double count; const float* gamma; const float* beta; float eps, momentum; float* running_mean; float* running_var; int64_t* nbt;
+  float* mean; float* invstd; float* scale; float* shift;
+};
+__device__ __forceinline__ void finalize_train_tail(const TrainTail& t, int c, double s1, double s2) {
+  const double count = t.count;
+  const double mu = s1 / count;
+  double var = s2 / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float inv = (float)(1.0 / sqrt(var + (double)t.eps));
+  const float g = t.gamma ? t.gamma[c] : 1.f, b = t.beta ? t.beta[c] : 0.f;
+  const float muf = (float)mu;
+  t.mean[c] = muf;
+  t.invstd[c] = inv;
+  const float sc = g * inv;
+  t.scale[c] = sc;
+  t.shift[c] = fmaf(-muf, sc, b);
+  if (t.running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    t.running_mean[c] = (float)((1.0 - t.momentum) * (double)t.running_mean[c] + t.momentum * mu);
+    t.running_var[c] = (float)((1.0 - t.momentum) * (double)t.running_var[c] + t.momentum * unbiased);
+  }
+  if (t.nbt && c == 0) *t.nbt += 1;
+}
+__global__ __launch_bounds__(FCW * FRL) void bn_finalize_train_kernel(const float* partial, int rows, int rstep, int C, int pstride, TrainTail t) {
   __shared__ double sm[FRL][2][FCW];
   const int c = blockIdx.x * FCW + threadIdx.x;
   double s1, s2;
   reduce_slab2(partial, rows, rstep, C, pstride, c, s1, s2, sm);
   if (threadIdx.y != 0 || c >= C) return;
-  const double mu = s1 / count;
-  double var = s2 / count - mu * mu;
-  if (var < 0.0) var = 0.0;
-  const float inv = (float)(1.0 / sqrt(var + (double)eps));
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-  const float muf = (float)mu;
-  mean[c] = muf;
-  invstd[c] = inv;
-  const float sc = g * inv;
-  scale[c] = sc;
-  shift[c] = fmaf(-muf, sc, b);
-  if (running_mean) {
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
-    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
-  }
-  if (nbt && c == 0) *nbt += 1;
+  finalize_train_tail(t, c, s1, s2);
+}
+__global__ __launch_bounds__(TL) void bn_finalize_train_tall_kernel(const float* partial, int rows, int rstep, int pstride, TrainTail t) {
+  __shared__ double sm[TL][8];
+  __shared__ double sg[8][8];
+  double s1, s2;
+  if (reduce_slab2_tall(partial, rows, rstep, pstride, blockIdx.x * 4, s1, s2, sm, sg)) finalize_train_tail(t, blockIdx.x * 4 + threadIdx.x, s1, s2);
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -132,31 +207,42 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
   shift[c] = fmaf(-rm[c], sc, b);
 }
 
-__global__ __launch_bounds__(FCW * FRL) void bn_bwd_finalize_kernel(const float* partial, int rows, int rstep, int C, int pstride, double count, const float* gamma,
-                                       const float* mean, const float* invstd, int training, float* dgamma,
-                                       float* dbeta, float* al, float* be, float* ga, float* dbias) {
+struct BwdTail {
+  double count; const float* gamma; const float* mean; const float* invstd; int training; float* dgamma; float* dbeta; float* al; float* be;
+  float* ga; float* dbias;
+};
+__device__ __forceinline__ void bwd_finalize_tail(const BwdTail& t, int c, double s1, double s2) {
+  if (t.dbeta) t.dbeta[c] = (float)s1;
+  if (t.dgamma) t.dgamma[c] = (float)s2;
+  const double g = t.gamma ? (double)t.gamma[c] : 1.0;
+  const double inv = (double)t.invstd[c], mu = (double)t.mean[c];
+  const double a = g * inv;
+  if (t.training) {
+    const double c1 = s1 / t.count, c2 = s2 / t.count;
+    t.al[c] = (float)a;
+    t.be[c] = (float)(-a * c2 * inv);
+    t.ga[c] = (float)(a * (c2 * inv * mu - c1));
+    if (t.dbias) t.dbias[c] = 0.f;      // sum_m dy_raw == 0 identically under batch statistics
+  } else {
+    t.al[c] = (float)a;
+    t.be[c] = 0.f;
+    t.ga[c] = 0.f;
+    if (t.dbias) t.dbias[c] = (float)(a * s1);
+  }
+}
+__global__ __launch_bounds__(FCW * FRL) void bn_bwd_finalize_kernel(const float* partial, int rows, int rstep, int C, int pstride, BwdTail t) {
   __shared__ double sm[FRL][2][FCW];
   const int c = blockIdx.x * FCW + threadIdx.x;
   double s1, s2;
   reduce_slab2(partial, rows, rstep, C, pstride, c, s1, s2, sm);
   if (threadIdx.y != 0 || c >= C) return;
-  if (dbeta) dbeta[c] = (float)s1;
-  if (dgamma) dgamma[c] = (float)s2;
-  const double g = gamma ? (double)gamma[c] : 1.0;
-  const double inv = (double)invstd[c], mu = (double)mean[c];
-  const double a = g * inv;
-  if (training) {
-    const double c1 = s1 / count, c2 = s2 / count;
-    al[c] = (float)a;
-    be[c] = (float)(-a * c2 * inv);
-    ga[c] = (float)(a * (c2 * inv * mu - c1));
-    if (dbias) dbias[c] = 0.f;          // sum_m dy_raw == 0 identically under batch statistics
-  } else {
-    al[c] = (float)a;
-    be[c] = 0.f;
-    ga[c] = 0.f;
-    if (dbias) dbias[c] = (float)(a * s1);
-  }
+  bwd_finalize_tail(t, c, s1, s2);
+}
+__global__ __launch_bounds__(TL) void bn_bwd_finalize_tall_kernel(const float* partial, int rows, int rstep, int pstride, BwdTail t) {
+  __shared__ double sm[TL][8];
+  __shared__ double sg[8][8];
+  double s1, s2;
+  if (reduce_slab2_tall(partial, rows, rstep, pstride, blockIdx.x * 4, s1, s2, sm, sg)) bwd_finalize_tail(t, blockIdx.x * 4 + threadIdx.x, s1, s2);
 }
 
 struct ApplyArgs {
@@ -225,6 +311,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdReduceArgs a) {
   }
 }
 
+// the four-channel form where the slab is tall enough for it to pay (KD_BN_TALL=0: never -- the A/B switch of tools/)
+bool slab_is_tall(const float* partial, int rows, int C, int pstride) {
+  static const int min_rows = [] { const char* e = getenv("KD_BN_TALL"); return e ? atoi(e) : 1024; }();
+  return min_rows > 0 && rows >= min_rows && C % 4 == 0 && pstride % 4 == 0 && kd_aligned16(partial);
+}
+
 }  // namespace
 
 extern "C" {
@@ -236,9 +328,12 @@ int kd_bn_finalize_train(float* partial, int rows, int C, int pstride, int64_t c
                          float* mean, float* invstd, float* scale, float* shift, void* stream) {
   KD_REQUIRE(partial && rows > 0 && C > 0 && pstride >= C && count > 0 && mean && invstd && scale && shift, KD_ERR_ARG, "kd_bn_finalize_train: bad args");
   const int rstep = slab_prereduce(partial, rows, C, pstride, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + FCW - 1) / FCW), dim3(FCW, FRL), 0, (hipStream_t)stream, partial, rows,
-                     rstep, C, pstride, (double)count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd, scale,
-                     shift);
+  const TrainTail t{(double)count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd, scale, shift};
+  if (slab_is_tall(partial, rows, C, pstride))
+    hipLaunchKernelGGL(bn_finalize_train_tall_kernel, dim3(C / 4), dim3(TL), 0, (hipStream_t)stream, partial, rows, rstep, pstride, t);
+  else
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + FCW - 1) / FCW), dim3(FCW, FRL), 0, (hipStream_t)stream, partial, rows, rstep, C,
+                       pstride, t);
   return kd_check_launch("kd_bn_finalize_train");
 }
 
@@ -291,8 +386,12 @@ int kd_bn_bwd_finalize(float* partial, int rows, int C, int pstride, int64_t cou
                        float* ga, float* dbias, void* stream) {
   KD_REQUIRE(partial && rows > 0 && C > 0 && pstride >= C && count > 0 && mean && invstd && al && be && ga, KD_ERR_ARG, "kd_bn_bwd_finalize: bad args");
   const int rstep = slab_prereduce(partial, rows, C, pstride, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FCW - 1) / FCW), dim3(FCW, FRL), 0, (hipStream_t)stream, partial, rows,
-                     rstep, C, pstride, (double)count, gamma, mean, invstd, training, dgamma, dbeta, al, be, ga, dbias);
+  const BwdTail t{(double)count, gamma, mean, invstd, training, dgamma, dbeta, al, be, ga, dbias};
+  if (slab_is_tall(partial, rows, C, pstride))
+    hipLaunchKernelGGL(bn_bwd_finalize_tall_kernel, dim3(C / 4), dim3(TL), 0, (hipStream_t)stream, partial, rows, rstep, pstride, t);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FCW - 1) / FCW), dim3(FCW, FRL), 0, (hipStream_t)stream, partial, rows, rstep, C,
+                       pstride, t);
   return kd_check_launch("kd_bn_bwd_finalize");
 }
 

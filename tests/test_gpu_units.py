@@ -576,3 +576,42 @@ def test_stem_inference_kernel_same_bits_as_two_passes(monkeypatch):
     assert set(res[True]) == set(res[False]) == {"stage2", "stage3", "stage4", "stage5"}
     for k in res[True]:
         assert torch.equal(res[True][k].view(torch.int32), res[False][k].view(torch.int32)), k
+
+
+@pytest.mark.parametrize("rows,C,pstride", [(5, 32, 32), (256, 128, 128), (1023, 64, 64), (1024, 32, 32), (2048, 192, 192), (5120, 128, 128),
+                                            (8192, 128, 256), (8192, 64, 64), (8193, 64, 64), (20000, 32, 32), (3000, 6, 6), (2048, 36, 40)])
+def test_bn_finalize_on_slabs_of_every_height(rows, C, pstride):
+    """kd_bn_finalize_train / kd_bn_bwd_finalize reduce a [rows][2][pstride] slab: short slabs (16 channels x 64 row lanes per workgroup),
+    tall ones (>= 1024 rows, C % 4 == 0: four channels x 256 row lanes), above 8192 rows a pre-reduction first.  Every class, plus channel
+    counts the tall form must refuse, against float64 sums of the same slab (BatchNorm2d training forward / backward, torch semantics)."""
+    from kdrt import ops
+    g = torch.Generator().manual_seed(rows * 7 + C)
+    slab = torch.randn(rows, 2, pstride, generator=g)
+    slab[:, 1] = slab[:, 1].abs() * 3 + 2.0                    # sum of squares: keeps the variance positive
+    count = rows * 10
+    s = slab.double().sum(0)[:, :C]
+    mu = s[0] / count
+    var = (s[1] / count - mu * mu).clamp_min(0)
+    bn = torch.nn.BatchNorm1d(C).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+    gam, bet = bn.weight.detach().double().cpu(), bn.bias.detach().double().cpu()
+    bnc = ops.BNC(C, torch.device("cuda"))
+    ops.bn_finalize_train(slab.cuda().contiguous(), rows, C, count, bn, bnc, pstride=pstride)
+    inv = 1.0 / torch.sqrt(var + bn.eps)
+    for got, want in ((bnc.mean, mu), (bnc.invstd, inv), (bnc.scale, gam * inv), (bnc.shift, bet - mu * gam * inv)):
+        assert max_err(got, want.float())[1] < 2e-6
+    assert max_err(bn.running_mean, (0.1 * mu).float())[1] < 2e-6
+    assert max_err(bn.running_var, (0.9 + 0.1 * var * count / (count - 1)).float())[1] < 2e-6
+    assert int(bn.num_batches_tracked) == 1
+    # backward coefficients from a second slab (sum G, sum G*xhat) with the statistics just produced
+    slab2 = torch.randn(rows, 2, pstride, generator=g)
+    t = slab2.double().sum(0)[:, :C]
+    dgamma, dbeta, abg, _ = ops.bn_bwd_finalize(slab2.cuda().contiguous(), rows, C, count, bn.weight, bnc, True, pstride=pstride)
+    assert max_err(dbeta, t[0].float())[1] < 2e-6 and max_err(dgamma, t[1].float())[1] < 2e-6
+    a = gam * bnc.invstd.double().cpu()
+    c1, c2 = t[0] / count, t[1] / count
+    i32, m32 = bnc.invstd.double().cpu(), bnc.mean.double().cpu()
+    for got, want in ((abg[0], a), (abg[1], -a * c2 * i32), (abg[2], a * (c2 * i32 * m32 - c1))):
+        assert max_err(got, want.float())[1] < 2e-6
