@@ -44,23 +44,26 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
     out[i] = t;
   }
 }
-// block (16 element quads, 16 split lanes) = 256 threads, 64 consecutive elements
-__global__ __launch_bounds__(256) void slab_reduce4_kernel(const float* __restrict__ slab, int nsplit, int64_t n,
-                                                          float* __restrict__ out) {
-  __shared__ float4 sm[16][16];
+// block (16 element quads, LY split lanes), 64 consecutive elements.  LY = 16 everywhere except tall, narrow slabs (the depthwise /
+// layer-0 / fusion weight gradients: 2048 rows of a few hundred to a few thousand elements, i.e. a handful of workgroups each walking
+// 128 rows per lane: 15-19 us per call in the r04 trace), which take 64 lanes.  The summation order depends on LY, LY only on (nsplit, n).
+template <int LY>
+__global__ __launch_bounds__(16 * LY) void slab_reduce4_kernel(const float* __restrict__ slab, int nsplit, int64_t n,
+                                                               float* __restrict__ out) {
+  __shared__ float4 sm[LY][16];
   const int64_t i = ((int64_t)blockIdx.x * 16 + threadIdx.x) * 4;
   float4 s = kd_zero4();
   if (i < n) {
     int k = threadIdx.y;
-    for (; k + 48 < nsplit; k += 64) {                       // four rows of this lane in flight, added in row order
-      const float4 a = kd_ld4(slab + (int64_t)k * n + i), b = kd_ld4(slab + (int64_t)(k + 16) * n + i);
-      const float4 c = kd_ld4(slab + (int64_t)(k + 32) * n + i), d = kd_ld4(slab + (int64_t)(k + 48) * n + i);
+    for (; k + 3 * LY < nsplit; k += 4 * LY) {               // four rows of this lane in flight, added in row order
+      const float4 a = kd_ld4(slab + (int64_t)k * n + i), b = kd_ld4(slab + (int64_t)(k + LY) * n + i);
+      const float4 c = kd_ld4(slab + (int64_t)(k + 2 * LY) * n + i), d = kd_ld4(slab + (int64_t)(k + 3 * LY) * n + i);
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
       s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
       s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
       s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
     }
-    for (; k < nsplit; k += 16) {
+    for (; k < nsplit; k += LY) {
       const float4 a = kd_ld4(slab + (int64_t)k * n + i);
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
@@ -69,8 +72,8 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(const float* __restri
   __syncthreads();
   if (threadIdx.y == 0 && i < n) {
     float4 t = kd_zero4();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { const float4 v = sm[k][threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+#pragma unroll 16
+    for (int k = 0; k < LY; ++k) { const float4 v = sm[k][threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
     kd_st4(out + i, t);
   }
 }
@@ -121,8 +124,12 @@ int kd_slab_reduce_tall_launch(float* slab, int rows, int64_t n, float* out, hip
 }
 
 int kd_slab_reduce_launch(const float* slab, int nsplit, int64_t n, float* out, hipStream_t st) {
-  if (n % 4 == 0 && kd_aligned16(slab) && kd_aligned16(out))
-    hipLaunchKernelGGL(slab_reduce4_kernel, dim3((unsigned)((n + 63) / 64)), dim3(16, 16), 0, st, slab, nsplit, n, out);
+  if (n % 4 == 0 && kd_aligned16(slab) && kd_aligned16(out)) {
+    if (nsplit >= 1024 && n <= 16384)
+      hipLaunchKernelGGL(slab_reduce4_kernel<64>, dim3((unsigned)((n + 63) / 64)), dim3(16, 64), 0, st, slab, nsplit, n, out);
+    else
+      hipLaunchKernelGGL(slab_reduce4_kernel<16>, dim3((unsigned)((n + 63) / 64)), dim3(16, 16), 0, st, slab, nsplit, n, out);
+  }
   else
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64, 16), 0, st, slab, nsplit, n, out);
   return kd_check_launch("kd_slab_reduce");

@@ -319,7 +319,7 @@ def test_inverted_residual_non_square(h, w, stride):
              seed=h + w)
 
 
-@pytest.mark.parametrize("shape", [(2, 13, 19, 8), (1, 70, 66, 72), (2, 33, 64, 384)])
+@pytest.mark.parametrize("shape", [(2, 13, 19, 8), (1, 70, 66, 72), (2, 33, 64, 384), (1, 192, 200, 32)])   # the last: a 1200-row slab (64-lane reduce)
 def test_dw_stride1_backward_forms_agree(shape):
     """The three forms of the stride-1 depthwise backward (separate data / weight kernels, fused column walk, fused tile
     kernel staged through LDS) on odd and tile-crossing shapes: same data gradient bits (identical fma order), weight
