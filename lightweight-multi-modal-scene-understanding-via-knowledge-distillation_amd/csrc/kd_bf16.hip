@@ -14,6 +14,7 @@
 #include "kd_common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -247,9 +248,18 @@ __device__ __forceinline__ float xor1(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
+#ifndef KD_BF16_PROBE
+#define KD_BF16_PROBE 0   // dev builds only: timing probes, results WRONG by construction (1: no C stores, 2: no A loads)
+#endif
+#ifndef KD_BF16_OCC
+#define KD_BF16_OCC 2
+#endif
+#ifndef KD_BF16_CH
+#define KD_BF16_CH 8
+#endif
 template <int NB, int AIN, int EPI>
-__global__ __launch_bounds__(64 * BW, 2) void pw_gemm_bf16_kernel(GemmBfArgs g) {
-  constexpr int N = 32 * NB, CH = 8;                                  // CH: k-steps (of 16) per register chunk
+__global__ __launch_bounds__(64 * BW, KD_BF16_OCC) void pw_gemm_bf16_kernel(GemmBfArgs g) {
+  constexpr int N = 32 * NB, CH = KD_BF16_CH;                         // CH: k-steps (of 16) per register chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Wh = reinterpret_cast<bf16_t*>(smem_raw);                   // [N][K] bf16, 16-byte chunks swizzled
   float* Co = reinterpret_cast<float*>(smem_raw + (size_t)N * g.K * 2);  // AIN 3: [7][K]
@@ -292,6 +302,9 @@ __global__ __launch_bounds__(64 * BW, 2) void pw_gemm_bf16_kernel(GemmBfArgs g) 
   // A fragment of k-step u for this lane: 8 consecutive k of row r starting at 16 u + 8 h
   auto load_frag = [&](int64_t gm, int u) -> u32x4 {
     if (AIN == 0) {
+#if KD_BF16_PROBE & 2
+      return u32x4{(uint32_t)gm, (uint32_t)u, 0x3f803f80u, 0x3f803f80u};
+#endif
       return ld16(reinterpret_cast<const bf16_t*>(g.A) + gm * g.lda + 16 * u + 8 * h);
     } else if (AIN == 1) {
       const float* p = reinterpret_cast<const float*>(g.A) + gm * g.lda + 16 * u + 8 * h;
@@ -367,7 +380,11 @@ __global__ __launch_bounds__(64 * BW, 2) void pw_gemm_bf16_kernel(GemmBfArgs g) 
           float lo = odd ? x1 : v0, hi = odd ? v1 : x0;
           const int64_t row = m0 + rbase + 4 * h + (odd ? 1 : 0);
           const int col = n0 + 32 * j + (r & ~1);
+#if KD_BF16_PROBE & 1
+          if (row < M && lo == 123456.75f) {
+#else
           if (row < M) {
+#endif
             if (g.res) {
               const uint32_t rr = *reinterpret_cast<const uint32_t*>(g.res + row * g.ldres + col);
               lo += bf_lo(rr); hi += bf_hi(rr);
@@ -403,6 +420,177 @@ __global__ __launch_bounds__(64 * BW, 2) void pw_gemm_bf16_kernel(GemmBfArgs g) 
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: second form of the same GEMM for the common case (A bf16, C bf16: AIN 0 / EPI 0), written after timing probes of the first
+// (tools/r4_probe_bf16.sh, -DKD_BF16_PROBE): over the 18 launches of a forward 3.59 ms, 2.03 ms without the C stores (and the residual
+// loads inside their guards), 2.56 ms without the A loads -- the layers with many output columns ran at 2.9-3.0 TB/s, the residual
+// layers (32 -> 32 at 4.2 M rows: 371 us, 86 without its epilogue) waited for one residual dword after the other, and the K = 32 / 64
+// layers had 2-4 KB per wave in flight.  What changed:
+//   * K is a template parameter (KU k-steps of 16), so the chunk structure of a slab is static and the loop bodies are branch-free;
+//   * the A fragments of the NEXT unit are requested before the current unit is multiplied, across slab boundaries; a unit is one
+//     chunk of eight k-steps, or for K = 32 / 64 four / two whole slabs (a "super-slab" of 128 / 64 consecutive rows): 8 KB per wave
+//     in flight for every K;
+//   * a residual tile is requested first thing in its unit (older than the prefetch in the in-order vmcnt queue), in the accumulator
+//     layout, so that the sum is rounded to bf16 once as before;
+//   * the epilogue goes through a wave-private LDS tile [32 rows][64 columns] (two column blocks per pass): dword writes in the
+//     accumulator layout, 16-byte reads along rows, 16-byte global stores -- whole 128-byte lines, 4 store instructions per pass
+//     instead of 16 (the fp32 streaming kernels' transposition tile, kd_gemm_stream_kernel.h);
+//   * full units run without predicates; the one partial unit of a launch is handled after the loop by the wave it falls to.
+// Same products, same fp32 accumulation order per output element, same single rounding: the same bits as the first form
+// (tests/test_gpu_bf16.py compares the two).  KD_BF16_V2=0 keeps the first form everywhere.
+template <int NB, int KU, bool RES>
+__global__ __launch_bounds__(64 * BW, 2) void pw_gemm_bf16_v2_kernel(GemmBfArgs g) {
+  constexpr int N = 32 * NB, K = 16 * KU, CPR = K / 8;
+  constexpr int SL = KU >= 8 ? 1 : 8 / KU;             // slabs per unit
+  constexpr int NCH = (KU + 7) / 8;                    // chunks of eight k-steps per slab (SL == 1)
+  constexpr int TWB = NB >= 2 ? 2 : 1;                 // column blocks per epilogue pass
+  constexpr int TP = 64 * TWB + 16;                    // tile row pitch, bytes
+  constexpr int LPR = 4 * TWB, RPI = 64 / LPR, NST = 32 / RPI;   // 16-byte phase: lanes per row, rows per instruction, instructions per pass
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Wh = reinterpret_cast<bf16_t*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const bool odd = (lane & 1) != 0;
+  const int n0 = blockIdx.y * N;
+  unsigned char* tile = smem_raw + (size_t)N * K * 2 + (size_t)wave * 32 * TP;
+  auto swz = [&](int n) { return CPR % 16 == 0 ? (n & 15) : (CPR % 16 == 8 ? ((n >> 1) & 7) : ((n >> 2) & 3)); };
+  for (int i = tid; i < N * K / 4; i += 64 * BW) {
+    const int n = i / (K / 4), k4 = i % (K / 4);
+    const float4 w = kd_ld4(g.W + (int64_t)(n0 + n) * K + k4 * 4);
+    bf16_t* d = Wh + n * K + ((k4 >> 1) ^ swz(n)) * 8 + (k4 & 1) * 4;
+    *reinterpret_cast<uint2*>(d) = make_uint2(pk_bf16(w.x, w.y), pk_bf16(w.z, w.w));
+  }
+  kd_lds_barrier();
+
+  const int M = (int)g.M;
+  constexpr int UR = 32 * SL;                          // rows per unit
+  const int nunit = (M + UR - 1) / UR, nfull = M / UR;
+  const int wtot = (int)gridDim.x * BW, wid = (int)blockIdx.x * BW + wave;
+  const int fsw = h ^ swz(r);
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+  const int lda = (int)g.lda, ldc = (int)g.ldc, ldres = (int)g.ldres;
+
+  float bias[NB], esc[NB], esh[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int c = n0 + 32 * j + r;
+    bias[j] = g.bias ? g.bias[c] : 0.f;
+    esc[j] = g.esc[c]; esh[j] = g.esh[c];
+  }
+
+  // the eight fragments of a unit: SL > 1: slab k, k-step u -> f[k * KU + u]; SL == 1: chunk c, k-steps 8 c .. 8 c + 7
+  auto issue = [&](int S, int c, u32x4 (&f)[8]) __attribute__((always_inline)) {
+    const int64_t m0 = (int64_t)S * UR;
+    const bf16_t* base = A + m0 * lda + 8 * h;                       // wave-uniform + a lane term that never changes
+    const int lim = (int)((int64_t)M - 1 - m0);                     // rows >= M of the partial unit repeat row M - 1
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+      const int rr = r + 32 * k;
+      const int off = (rr < lim ? rr : lim) * lda;
+#pragma unroll
+      for (int i = 0; i < (SL > 1 ? KU : 8); ++i) {
+        const int u = SL > 1 ? i : 8 * c + i;
+        if (u < KU) f[SL > 1 ? k * KU + i : i] = ld16(base + off + 16 * u);
+      }
+    }
+  };
+
+  u32x4 cur[8], nxt[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { cur[i] = u32x4{0u, 0u, 0u, 0u}; nxt[i] = u32x4{0u, 0u, 0u, 0u}; }
+
+  auto unit = [&](int S, auto full_tag) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const int64_t m0u = (int64_t)S * UR;
+    uint32_t rr[RES ? SL : 1][RES ? NB : 1][8];
+    if constexpr (RES) {                                             // first in the queue: the epilogue must not wait for the prefetch
+#pragma unroll
+      for (int k = 0; k < SL; ++k)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const bf16_t* rb = g.res + (m0u + 32 * k) * ldres + n0 + 32 * j + (r & ~1);
+#pragma unroll
+          for (int q = 0; q < 16; q += 2) {
+            int row = (q & 3) + 8 * (q >> 2) + 4 * h + (odd ? 1 : 0);
+            if (!FULL) { const int lim = (int)((int64_t)M - 1 - m0u - 32 * k); row = row < lim ? row : (lim > 0 ? lim : 0); }
+            rr[k][j][q >> 1] = *reinterpret_cast<const uint32_t*>(rb + row * ldres);
+          }
+        }
+    }
+    const int Sn = S + wtot < nunit ? S + wtot : S;                  // past the end: fetch this unit again (never used)
+    if constexpr (SL > 1) issue(Sn, 0, nxt);
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+      const int64_t m0 = m0u + 32 * k;
+      f32x16 acc[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if constexpr (SL == 1) {
+          if (c + 1 < NCH) issue(S, c + 1, nxt);
+          else issue(Sn, 0, nxt);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int u = SL > 1 ? i : 8 * c + i;
+          if ((SL > 1 ? i < KU : true) && u < KU) {
+            const u32x4 af = cur[SL > 1 ? k * KU + i : i];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+              const u32x4 bf = *reinterpret_cast<const u32x4*>(Wh + (32 * j + r) * K + ((2 * u) ^ fsw) * 8);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[j], 0, 0, 0);
+            }
+          }
+        }
+        if constexpr (SL == 1) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);               // chunks stay in program order: the unrolled chunk loop otherwise lets hipcc hoist
+      }                                                  // later chunks' B-fragment reads and run out of registers (K = 384 / 512, NB = 4)
+      // ---- epilogue of slab k: TWB column blocks per pass through the tile -------------------------------------------------
+#pragma unroll
+      for (int p = 0; p < NB / TWB; ++p) {
+#pragma unroll
+        for (int jj = 0; jj < TWB; ++jj) {
+          const int j = p * TWB + jj;
+#pragma unroll
+          for (int q = 0; q < 16; q += 2) {
+            const int rbase = (q & 3) + 8 * (q >> 2);
+            float v0 = kd_act(kd_affine(acc[j][q] + bias[j], esc[j], esh[j]), g.act);
+            float v1 = kd_act(kd_affine(acc[j][q + 1] + bias[j], esc[j], esh[j]), g.act);
+            float x0 = xor1(v0), x1 = xor1(v1);
+            asm volatile("" : "+v"(x0), "+v"(x1));
+            float lo = odd ? x1 : v0, hi = odd ? v1 : x0;
+            if constexpr (RES) { const uint32_t t = rr[k][j][q >> 1]; lo += bf_lo(t); hi += bf_hi(t); }
+            const int trow = rbase + 4 * h + (odd ? 1 : 0);
+            *reinterpret_cast<uint32_t*>(tile + trow * TP + (32 * jj + (r & ~1)) * 2) = pk_bf16(lo, hi);
+          }
+        }
+        bf16_t* cb = g.C + m0 * ldc + n0 + 32 * TWB * p;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+          const int trow = i * RPI + lane / LPR, ch = lane % LPR;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(tile + trow * TP + ch * 16);
+          if (FULL || m0 + trow < M) st16(cb + trow * ldc + ch * 8, v);
+        }
+      }
+    }
+    if constexpr (SL > 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    }
+  };
+
+  int S = wid;
+  if (S < nunit) issue(S, 0, cur);
+  for (; S < nfull; S += wtot) unit(S, std::true_type{});
+  if (S < nunit) unit(S, std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -512,7 +700,7 @@ template <int NB>
 int launch_gemm_bf16(GemmBfArgs& g, int ain, int epi, hipStream_t st) {
   const int ntiles = g.N / (32 * NB);
   int64_t want = (g.M + 32 * BW - 1) / (32 * BW);
-  int cap = 256 / ntiles; if (cap < 1) cap = 1;
+  int cap = 128 * KD_BF16_OCC / ntiles; if (cap < 1) cap = 1;
   const dim3 grid((unsigned)(want < cap ? want : cap), ntiles);
   const size_t lds = (size_t)32 * NB * g.K * 2 + (ain == 3 ? (size_t)7 * g.K * 4 : 0);
 #define KD_BCASE(A_, E_)                                                                                               \
@@ -526,6 +714,56 @@ int launch_gemm_bf16(GemmBfArgs& g, int ain, int epi, hipStream_t st) {
 #undef KD_BCASE
   kd_set_error("kd_bf16_pwconv: unsupported (input kind %d, epilogue %d)", ain, epi);
   return KD_ERR_ARG;
+}
+
+constexpr int KD_BF16_V2_NO_INSTANCE = -12345;
+template <int NB, int KU>
+int launch_gemm_bf16_v2_nk(GemmBfArgs& g, hipStream_t st) {
+  const int ntiles = g.N / (32 * NB);
+  constexpr int SL = KU >= 8 ? 1 : 8 / KU, TWB = NB >= 2 ? 2 : 1;
+  const int64_t want = (g.M + 32 * SL * BW - 1) / (32 * SL * BW);
+  int cap = 256 / ntiles; if (cap < 1) cap = 1;
+  const dim3 grid((unsigned)(want < cap ? want : cap), ntiles);
+  const size_t lds = (size_t)32 * NB * 16 * KU * 2 + (size_t)BW * 32 * (64 * TWB + 16);
+  const void* fn = g.res ? (const void*)pw_gemm_bf16_v2_kernel<NB, KU, true> : (const void*)pw_gemm_bf16_v2_kernel<NB, KU, false>;
+  const hipError_t le = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  KD_REQUIRE(le == hipSuccess, (int)le, "kd_bf16_pwconv: cannot raise the dynamic LDS limit to %zu B: %s", lds, hipGetErrorString(le));
+  if (g.res) hipLaunchKernelGGL((pw_gemm_bf16_v2_kernel<NB, KU, true>), grid, dim3(64 * BW), lds, st, g);
+  else hipLaunchKernelGGL((pw_gemm_bf16_v2_kernel<NB, KU, false>), grid, dim3(64 * BW), lds, st, g);
+  return kd_check_launch("kd_bf16_pwconv");
+}
+template <int NB>
+int launch_gemm_bf16_v2_n(GemmBfArgs& g, hipStream_t st) {
+  switch (g.K / 16) {
+    case 2: return launch_gemm_bf16_v2_nk<NB, 2>(g, st);
+    case 4: return launch_gemm_bf16_v2_nk<NB, 4>(g, st);
+    case 8: return launch_gemm_bf16_v2_nk<NB, 8>(g, st);
+    case 12: return launch_gemm_bf16_v2_nk<NB, 12>(g, st);
+    case 16: return launch_gemm_bf16_v2_nk<NB, 16>(g, st);
+    case 24: return launch_gemm_bf16_v2_nk<NB, 24>(g, st);
+    case 32: return launch_gemm_bf16_v2_nk<NB, 32>(g, st);
+    case 48: return launch_gemm_bf16_v2_nk<NB, 48>(g, st);
+  }
+  return KD_BF16_V2_NO_INSTANCE;
+}
+// the second form where it has an instance: K in {32, 64, 128, 192, 256, 384, 512, 768}, 16-byte-aligned rows of C, fewer than 2^31 rows
+int launch_gemm_bf16_v2(GemmBfArgs& g, hipStream_t st) {
+  static const int on = [] { const char* e = getenv("KD_BF16_V2"); return e ? atoi(e) : 1; }();
+  if (!on || g.K % 16 != 0 || g.M >= ((int64_t)1 << 31) || g.ldc % 8 != 0 || !kd_aligned16(g.C) || g.lda * 128 >= ((int64_t)1 << 31) ||
+      g.ldc * 32 >= ((int64_t)1 << 31) || (g.res && g.ldres * 32 >= ((int64_t)1 << 31)))
+    return KD_BF16_V2_NO_INSTANCE;
+  const int SL = g.K >= 128 ? 1 : 128 / g.K;
+  const size_t budget = 160 * 1024;
+  for (int NB = 4; NB >= 1; NB >>= 1) {
+    if (g.N % (32 * NB) != 0) continue;
+    const size_t lds = (size_t)32 * NB * g.K * 2 + (size_t)BW * 32 * (64 * (NB >= 2 ? 2 : 1) + 16);
+    if (lds > budget) continue;
+    if (g.res && SL * NB * 8 > 32) continue;                         // the residual tile lives in registers for the whole unit
+    if (NB == 4) return launch_gemm_bf16_v2_n<4>(g, st);
+    if (NB == 2) return launch_gemm_bf16_v2_n<2>(g, st);
+    return launch_gemm_bf16_v2_n<1>(g, st);
+  }
+  return KD_BF16_V2_NO_INSTANCE;
 }
 
 }  // namespace
@@ -577,6 +815,10 @@ int kd_bf16_pwconv(const void* A, int64_t lda, int a_kind, const float* W, const
   GemmBfArgs g{A, lda, W, bias, esc, esh, act, (bf16_t*)C, ldc, (const bf16_t*)res, ldres, M, K, N, m_dev, l0w, l0b, sc0, sh0, act0,
                cell, grid, ldgrid};
   hipStream_t st = (hipStream_t)stream;
+  if (a_kind == 0 && epi == 0 && !m_dev) {
+    const int rc = launch_gemm_bf16_v2(g, st);
+    if (rc != KD_BF16_V2_NO_INSTANCE) return rc;
+  }
   // widest column tile whose W image (32 NB x K bf16) fits beside the coefficient tables in 96 KB of LDS
   const size_t budget = 96 * 1024;
   if (N % 128 == 0 && (size_t)128 * K * 2 <= budget) return launch_gemm_bf16<4>(g, a_kind, epi, st);

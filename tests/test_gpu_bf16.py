@@ -127,3 +127,36 @@ def test_bf16_one_kernel_lidar_encoder_against_the_two_launches(monkeypatch):
     print(f"one-kernel bf16 LiDAR encoder vs two launches: max |diff| = {err:.2e} of the map's maximum")
     assert err <= 4e-3
     assert (one["logits"] - two["logits"]).abs().max().item() <= 1e-2 * (two["logits"].max() - two["logits"].min()).item()
+
+
+@pytest.mark.parametrize("M,K,N,res,sliced", [(4096, 32, 32, True, False), (4100, 32, 192, False, False), (1000, 64, 384, False, False),
+                                              (777, 64, 64, True, False), (5000, 128, 128, True, True), (3001, 192, 64, False, False),
+                                              (2049, 256, 128, False, True), (1111, 384, 64, True, False), (2500, 384, 128, False, False),
+                                              (900, 512, 128, False, False), (1300, 768, 128, True, False), (31, 128, 768, False, False),
+                                              (130, 32, 32, True, False), (64, 64, 96, False, False)])
+def test_bf16_gemm_second_form_same_bits_as_the_first(M, K, N, res, sliced):
+    """kd_bf16_pwconv has two kernels for bf16 in / bf16 out: the round-4 form (K static, prefetch across slabs, residual tile requested
+    first, 16-byte stores through an LDS tile) and the first form, which still serves fp32 inputs, the LiDAR layers and any launch given a
+    device-side row count.  Same products, same accumulation order, one rounding: the outputs must be bit-identical -- on every K the
+    second form has an instance for, ragged M (partial units), residuals, and C as a column slice of a wider buffer."""
+    from kdrt.lib import lib
+    from kdrt.ops import P, stream
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    rnd = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    A = rnd(M, K).bfloat16()
+    W, b, sc, sh = rnd(N, K) * 0.2, rnd(N), rnd(N).abs() + 0.5, rnd(N) * 0.3
+    R = rnd(M, N).bfloat16() if res else None
+    outs = []
+    for first_form in (False, True):
+        wide = torch.full((M, 2 * N if sliced else N), 7.0, device="cuda", dtype=torch.bfloat16)
+        out = wide[:, N:] if sliced else wide
+        mdev = torch.tensor([M], device="cuda", dtype=torch.int32) if first_form else None     # a device-side M selects the first form
+        lib.call("kd_bf16_pwconv", P(A), K, 0, P(W), P(b), P(sc), P(sh), 2, P(out), out.stride(0), P(R), N if res else 0, 0, M, K, N,
+                 P(mdev), None, None, None, None, 0, None, None, 0, stream())
+        torch.cuda.synchronize()
+        if sliced:
+            assert bool((wide[:, :N] == 7.0).all())                    # the neighbouring columns are untouched
+        outs.append(out.float().clone())
+    assert torch.equal(outs[0], outs[1])
+    want = torch.clamp((A.float() @ W.bfloat16().float().t() + b) * sc + sh, 0.0, 6.0) + (R.float() if res else 0.0)
+    assert (outs[0] - want).abs().max().item() <= 0.02 * max(1.0, want.abs().max().item())      # bf16 output rounding
