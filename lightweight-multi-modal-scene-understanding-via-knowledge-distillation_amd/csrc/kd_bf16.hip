@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void stem_bf16_v2_kernel(const float* __restri
 
 // ---------------------------------------------------------------------------------------------------------------------
 // depthwise 3x3 (stride 1 / 2, pad 1) on an ACTIVATED bf16 input; output act(conv * scale + shift) as bf16.
-// A thread owns 8 channels (16 bytes) of a column segment and slides a 3-row window down it; taps in LDS ([tap][C]).
+// A thread owns 8 channels (16 bytes) of a column segment and slides a 3-row window down it; its 72 taps in registers.
 struct DwBfArgs {
   const bf16_t* x; const float* w; const float* sc; const float* sh; int act; bf16_t* y;
   int B, H, W, C, Ho, Wo, stride, groups, slots;
@@ -174,24 +174,26 @@ __device__ __forceinline__ void dwb_unpack_row(const Raw3& q, Row8& o) {
 
 template <int STRIDE>
 __global__ __launch_bounds__(256) void dw_bf16_kernel(DwBfArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];      // [9][C]
   const int tid = threadIdx.x;
-  for (int i = tid; i < a.C * 9; i += 256) wl[(i % 9) * a.C + i / 9] = a.w[i];
-  __syncthreads();
   const int gidx = tid % a.groups, slot = tid / a.groups;
   if (slot >= a.slots) return;
   const int c0 = gidx * 8;
   float sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { sc[j] = a.sc[c0 + j]; sh[j] = a.sh[c0 + j]; }
+  // A thread's eight channels never change: its 72 taps live in registers for the whole launch.  (Rounds 3-4 kept them in LDS as
+  // [tap][C] and read 18 x 16 B per output row: at 32 B of HBM traffic per output the stride-1 launches were bound by those reads and
+  // the VALU work together -- 2.6-3.4 TB/s where the stride-2 launches, 80 B per output, ran at 4.2-4.6.)
+  float wt[9][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t][j] = a.w[(c0 + j) * 9 + t];
   const int nseg = (a.Ho + DWB_SEG - 1) / DWB_SEG;
   const int64_t items = (int64_t)a.B * nseg * a.Wo;
-  auto fma_row = [&](float (&acc)[8], const Row8& r, int kh) {
-    const float* w0 = wl + (kh * 3 + 0) * a.C + c0;
-    const float* w1 = wl + (kh * 3 + 1) * a.C + c0;
-    const float* w2 = wl + (kh * 3 + 2) * a.C + c0;
+  auto fma_row = [&](float (&acc)[8], const Row8& r, int kh) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = fmaf(r.l[j], w0[j], fmaf(r.c[j], w1[j], fmaf(r.r[j], w2[j], acc[j])));
+    for (int j = 0; j < 8; ++j) acc[j] = fmaf(r.l[j], wt[kh * 3 + 0][j], fmaf(r.c[j], wt[kh * 3 + 1][j], fmaf(r.r[j], wt[kh * 3 + 2][j], acc[j])));
   };
   for (int64_t it = (int64_t)blockIdx.x * a.slots + slot; it < items; it += (int64_t)gridDim.x * a.slots) {
     const int wo = (int)(it % a.Wo), sg = (int)((it / a.Wo) % nseg), b = (int)(it / ((int64_t)a.Wo * nseg));
@@ -224,6 +226,74 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(DwBfArgs a) {
       st16(a.y + (((int64_t)b * a.Ho + ho) * a.Wo + wo) * a.C + c0, pack8(acc));
       if (STRIDE == 1) { r0 = r1; r1 = r2; } else { r0 = r2; }
     }
+  }
+}
+
+// Stride 1, round 4: the same arithmetic as ONE software pipeline over all the column segments of a thread.  In the kernel above every
+// segment of 16 output rows starts cold (two halo rows are fetched and waited for before the first output row, and the last two
+// prefetches of a segment are rows nobody uses): the stride-1 launches ran at 2.6-3.4 TB/s, the stride-2 ones (80 B per output
+// against 32) at 4.2-4.6.  Here a segment is SEG + 2 row arrivals; the row two arrivals ahead is always in flight, and during the last
+// two arrivals of a segment those are rows 0 and 1 of the thread's NEXT segment.  The arrival loop is fully unrolled (no control flow
+// between the loads: the in-order vmcnt waits stay exact), the window rotates by renaming.  Ho must be a multiple of SEG (16 or 8).
+template <int SEG>
+__global__ __launch_bounds__(256) void dw_bf16_s1_pipe_kernel(DwBfArgs a) {
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  if (slot >= a.slots) return;
+  const int c0 = gidx * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = a.sc[c0 + j]; sh[j] = a.sh[c0 + j]; }
+  float wt[9][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t][j] = a.w[(c0 + j) * 9 + t];
+  const int nseg = a.Ho / SEG;
+  const int64_t items = (int64_t)a.B * nseg * a.Wo, stride = (int64_t)gridDim.x * a.slots;
+  int64_t it = (int64_t)blockIdx.x * a.slots + slot;
+  if (it >= items) return;
+  auto coords = [&](int64_t t, int& b, int& h0, int& wo) __attribute__((always_inline)) {
+    wo = (int)(t % a.Wo);
+    const int64_t q = t / a.Wo;
+    h0 = (int)(q % nseg) * SEG;
+    b = (int)(q / nseg);
+  };
+  int b, h0, wo;
+  coords(it, b, h0, wo);
+  Raw3 qa = dwb_issue_row(a, b, h0 - 1, wo, c0), qb = dwb_issue_row(a, b, h0, wo, c0);
+  Row8 r0, r1, r2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { r1.l[j] = r1.c[j] = r1.r[j] = 0.f; r2.l[j] = r2.c[j] = r2.r[j] = 0.f; }
+  for (;;) {
+    const int64_t itn = it + stride;
+    const bool more = itn < items;
+    int bn, h0n, won;
+    coords(more ? itn : it, bn, h0n, won);
+#pragma unroll
+    for (int k = 0; k < SEG + 2; ++k) {                        // arrival k is input row h0 - 1 + k
+      const Raw3 c = qa;
+      qa = qb;
+      if (k + 2 < SEG + 2) qb = dwb_issue_row(a, b, h0 + 1 + k, wo, c0);
+      else qb = dwb_issue_row(a, bn, h0n - 1 + (k - SEG), won, c0);          // rows 0, 1 of the next segment
+      r0 = r1; r1 = r2;
+      dwb_unpack_row(c, r2);
+      if (k >= 2) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const Row8& rw = kh == 0 ? r0 : (kh == 1 ? r1 : r2);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            acc[j] = fmaf(rw.l[j], wt[kh * 3 + 0][j], fmaf(rw.c[j], wt[kh * 3 + 1][j], fmaf(rw.r[j], wt[kh * 3 + 2][j], acc[j])));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = kd_act(kd_affine(acc[j], sc[j], sh[j]), a.act);
+        st16(a.y + (((int64_t)b * a.Ho + (h0 + k - 2)) * a.Wo + wo) * a.C + c0, pack8(acc));
+      }
+    }
+    if (!more) break;
+    it = itn; b = bn; h0 = h0n; wo = won;
   }
 }
 
@@ -792,9 +862,17 @@ int kd_bf16_dwconv3x3(const void* x, const float* w, const float* sc, const floa
   int groups, slots;
   const int grid = cg8_layout((int64_t)B * ((Ho + DWB_SEG - 1) / DWB_SEG) * Wo, C, groups, slots);
   DwBfArgs a{(const bf16_t*)x, w, sc, sh, act, (bf16_t*)y, B, H, W, C, Ho, Wo, stride, groups, slots};
-  const size_t lds = (size_t)C * 9 * sizeof(float);
-  if (stride == 1) hipLaunchKernelGGL(dw_bf16_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(dw_bf16_kernel<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  static const int pipe = [] { const char* e = getenv("KD_BF16_DW_PIPE"); return e ? atoi(e) : 1; }();
+  if (stride == 1 && pipe && Ho % 16 == 0) {
+    const int g16 = cg8_layout((int64_t)B * (Ho / 16) * Wo, C, groups, slots);
+    a.groups = groups; a.slots = slots;
+    hipLaunchKernelGGL(dw_bf16_s1_pipe_kernel<16>, dim3(g16), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (stride == 1 && pipe && Ho % 8 == 0) {
+    const int g8 = cg8_layout((int64_t)B * (Ho / 8) * Wo, C, groups, slots);
+    a.groups = groups; a.slots = slots;
+    hipLaunchKernelGGL(dw_bf16_s1_pipe_kernel<8>, dim3(g8), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (stride == 1) hipLaunchKernelGGL(dw_bf16_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(dw_bf16_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return kd_check_launch("kd_bf16_dwconv3x3");
 }
 

@@ -160,3 +160,26 @@ def test_bf16_gemm_second_form_same_bits_as_the_first(M, K, N, res, sliced):
     assert torch.equal(outs[0], outs[1])
     want = torch.clamp((A.float() @ W.bfloat16().float().t() + b) * sc + sh, 0.0, 6.0) + (R.float() if res else 0.0)
     assert (outs[0] - want).abs().max().item() <= 0.02 * max(1.0, want.abs().max().item())      # bf16 output rounding
+
+
+@pytest.mark.parametrize("B,H,W,C,stride", [(2, 16, 9, 32, 1), (3, 48, 20, 8, 1), (1, 24, 7, 384, 1), (2, 20, 11, 64, 1), (1, 64, 64, 192, 1),
+                                            (2, 8, 5, 768, 1), (2, 32, 18, 32, 2), (1, 17, 9, 64, 2)])
+def test_bf16_depthwise_forms_against_torch(B, H, W, C, stride):
+    """kd_bf16_dwconv3x3: stride 1 runs as one software pipeline over a thread's column segments where Ho is a multiple of 16 or 8 (one,
+    several and many segments per column here), otherwise -- and for stride 2 -- segment by segment.  Against F.conv2d on the same bf16
+    input in fp32: the result is rounded to bf16 once, so the two may differ by one bf16 ulp where the fp32 sums differ in the last bits."""
+    import torch.nn.functional as F
+    from kdrt.lib import lib
+    from kdrt.ops import P, stream
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H * 10 + C)
+    rnd = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    x = rnd(B, H, W, C).bfloat16()
+    w, sc, sh = rnd(C, 1, 3, 3) * 0.3, rnd(C).abs() + 0.5, rnd(C) * 0.2
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.full((B, Ho, Wo, C), 9.0, device="cuda", dtype=torch.bfloat16)
+    lib.call("kd_bf16_dwconv3x3", P(x), P(w), P(sc), P(sh), 2, P(y), B, H, W, C, stride, stream())
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, stride=stride, padding=1, groups=C)
+    ref = torch.clamp(ref * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1), 0.0, 6.0).permute(0, 2, 3, 1)
+    err = (y.float() - ref).abs()
+    assert bool((err <= 2.0 ** -7 * ref.abs() + 1e-6).all()), float(err.max())
