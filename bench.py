@@ -190,7 +190,7 @@ def bf16_forward_bench(args, dev, images, pts, steps):
         f[0] += flops; f[1] += nbytes; f[2] += secs; f[3] += 1
     top = max(fam, key=lambda k: fam[k][2])
     tot_b, tot_s = sum(f[1] for f in fam.values()), sum(f[2] for f in fam.values())
-    roof = {"bound": "hbm", "kernel": {"bf16_pw": "pw_gemm_bf16_kernel (1x1 conv / point MLP, one bf16 MFMA product per element)",
+    roof = {"bound": "hbm", "kernel": {"bf16_pw": "pw_gemm_bf16_v2_kernel / pw_gemm_bf16_kernel (1x1 conv / point MLP, one bf16 MFMA product per element)",
                                        "bf16_dw": "dw_bf16_kernel (depthwise 3x3)"}.get(top, top),
             "achieved": round(fam[top][1] / fam[top][2] / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(fam[top][1] / fam[top][2] / 1e9 / HBM_PEAK_GBPS, 4), "launches": fam[top][3],
