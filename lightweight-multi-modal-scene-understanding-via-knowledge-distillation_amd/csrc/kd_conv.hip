@@ -395,6 +395,89 @@ __global__ __launch_bounds__(256) void dw_fwd_sw_kernel(DwArgs a) {
   if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots, bx, cbase);
 }
 
+// Stride 1, round 4: the same window arithmetic as ONE software pipeline over all the column segments of a thread (the form that took the
+// bf16 depthwise kernel from 3.3 to 4.4 TB/s, kd_bf16.hip).  Above, every segment starts cold -- two rows are loaded and waited for before
+// the first output row -- and every output row waits for the row it has just requested; 16 waves per CU cover that to ~5.4 TB/s.  Here a
+// segment is SEG + 2 row arrivals, the raw row two arrivals ahead is always in flight (during the last two arrivals of a segment: rows
+// 0 and 1 of the thread's next segment), and the arrival loop is fully unrolled: no control flow between the loads, exact vmcnt waits,
+// the window rotates by renaming.  Same fma order per output as dw_fwd_sw_kernel<1>: the same bits.  Ho must be a multiple of SEG.
+template <int SEG>
+__global__ __launch_bounds__(256) void dw_fwd_pipe_s1_kernel(DwArgs a) {
+  __shared__ float red[2 * 256 * 4];
+  const int tid = threadIdx.x;
+  const int gidx = tid % a.groups, slot = tid / a.groups;
+  const int bx = blockIdx.x / a.nchunk, nbx = gridDim.x / a.nchunk, cbase = (blockIdx.x % a.nchunk) * a.groups * 4;
+  const int c0 = cbase + gidx * 4;
+  float4 s1 = kd_zero4(), s2 = kd_zero4();
+  const int nseg = a.Ho / SEG;
+  const int64_t items = (int64_t)a.B * nseg * a.Wo, stride = (int64_t)nbx * a.slots;
+  int64_t it = (int64_t)bx * a.slots + slot;
+  if (slot < a.slots && it < items) {
+    float wreg[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wreg[j][t] = a.w[(c0 + j) * 9 + t];
+    const bool deferred = a.sc != nullptr;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = kd_zero4();
+    if (deferred) { sc = kd_ld4(a.sc + c0); sh = kd_ld4(a.sh + c0); }
+    auto coords = [&](int64_t t, int& b, int& h0, int& wo) __attribute__((always_inline)) {
+      wo = (int)(t % a.Wo);
+      const int64_t q = t / a.Wo;
+      h0 = (int)(q % nseg) * SEG;
+      b = (int)(q / nseg);
+    };
+    // a raw row by 32-bit element offsets from a.x (the host checks the tensor has fewer than 2^31 elements); `hi` passes through an
+    // opaque asm so that hipcc computes each arrival's addresses when it issues them (left alone it precomputes all 18 x 3 pointers of a
+    // segment: 218 registers, two waves per SIMD)
+    auto issue = [&](int bb, int hi, int wi) __attribute__((always_inline)) -> DwRow {
+      asm volatile("" : "+v"(hi));
+      const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi);
+      const uint32_t ro = (uint32_t)((bb * a.H + hic) * a.W) * (uint32_t)a.C + (uint32_t)c0;
+      const int wl = wi - 1 < 0 ? 0 : wi - 1, wr_ = wi + 1 >= a.W ? a.W - 1 : wi + 1;
+      DwRow o;
+      o.l = kd_ld4(a.x + (ro + (uint32_t)(wl * a.C))); o.c = kd_ld4(a.x + (ro + (uint32_t)(wi * a.C))); o.r = kd_ld4(a.x + (ro + (uint32_t)(wr_ * a.C)));
+      return o;
+    };
+    int b, h0, wo;
+    coords(it, b, h0, wo);
+    DwRow qa = issue(b, h0 - 1, wo), qb = issue(b, h0, wo);
+    DwRow r0, r1, r2;
+    r1.l = r1.c = r1.r = kd_zero4();
+    r2.l = r2.c = r2.r = kd_zero4();
+    for (;;) {
+      const int64_t itn = it + stride;
+      const bool more = itn < items;
+      int bn, h0n, won;
+      coords(more ? itn : it, bn, h0n, won);
+#pragma unroll
+      for (int k = 0; k < SEG + 2; ++k) {                      // arrival k is input row h0 - 1 + k
+        const DwRow c = qa;
+        qa = qb;
+        if (k + 2 < SEG + 2) qb = issue(b, h0 + 1 + k, wo);
+        else qb = issue(bn, h0n - 1 + (k - SEG), won);                                       // rows 0, 1 of the next segment
+        r0 = r1; r1 = r2;
+        r2 = dw_finish_row(c, deferred, sc, sh, a.act, h0 - 1 + k, wo, a.H, a.W);
+        if (k >= 2) {
+          float4 acc = kd_zero4();
+          dw_fma_row(acc, r0, wreg, 0);
+          dw_fma_row(acc, r1, wreg, 1);
+          dw_fma_row(acc, r2, wreg, 2);
+          float* dst = a.y + (((int64_t)b * a.Ho + (h0 + k - 2)) * a.Wo + wo) * a.C + c0;
+          if (a.nt) kd_st4_nt(dst, acc); else kd_st4(dst, acc);
+          s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+          s2.x = fmaf(acc.x, acc.x, s2.x); s2.y = fmaf(acc.y, acc.y, s2.y);
+          s2.z = fmaf(acc.z, acc.z, s2.z); s2.w = fmaf(acc.w, acc.w, s2.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);                     // arrivals stay in program order (unpinned, hipcc hoists the address
+      }                                                        // arithmetic of all 18 arrivals: 218 registers, two waves per SIMD)
+      if (!more) break;
+      it = itn; b = bn; h0 = h0n; wo = won;
+    }
+  }
+  if (a.partial) dw_block_stats(red, s1, s2, a.partial, a.C, a.groups, a.slots, bx, cbase);
+}
+
 struct DwRaw { float4 d, y; };
 // raw (D, Y) at output pixel (ho, wo), indices clamped into the image (the caller zero-selects what was outside)
 __device__ __forceinline__ DwRaw dw_dy_raw_s1(const DwBwdArgs& a, int b, int ho, int wo, int c0) {
@@ -1172,7 +1255,11 @@ int kd_dwconv3x3_fwd(const float* x, const float* sc, const float* sh, int act, 
   const DwLayout l = dw_layout((int64_t)B * Ho * Wo, C);
   DwArgs a{x, sc, sh, act, w, y, partial, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk,
            kd_nt_store((size_t)B * Ho * Wo * C * sizeof(float))};
-  if (stride == 1) hipLaunchKernelGGL(dw_fwd_sw_kernel<1>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  static const int pipe = [] { const char* e = getenv("KD_DW_FWD_PIPE"); return e ? atoi(e) : 1; }();
+  const bool small = (int64_t)B * H * W * C < ((int64_t)1 << 31);      // the pipelined kernel addresses x by 32-bit element offsets
+  if (stride == 1 && pipe && small && Ho % 16 == 0) hipLaunchKernelGGL(dw_fwd_pipe_s1_kernel<16>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (stride == 1 && pipe && small && Ho % 8 == 0) hipLaunchKernelGGL(dw_fwd_pipe_s1_kernel<8>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (stride == 1) hipLaunchKernelGGL(dw_fwd_sw_kernel<1>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(dw_fwd_sw_kernel<2>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   return kd_check_launch("kd_dwconv3x3_fwd");
 }
