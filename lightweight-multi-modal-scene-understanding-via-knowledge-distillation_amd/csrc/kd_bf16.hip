@@ -580,12 +580,16 @@ __global__ __launch_bounds__(64 * BW, 2) void pw_gemm_bf16_v2_kernel(GemmBfArgs 
       for (int k = 0; k < SL; ++k)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-          const bf16_t* rb = g.res + (m0u + 32 * k) * ldres + n0 + 32 * j + (r & ~1);
+          const bf16_t* rb = g.res + (FULL ? (m0u + 32 * k) * ldres : (int64_t)0) + n0 + 32 * j + (r & ~1);
 #pragma unroll
           for (int q = 0; q < 16; q += 2) {
             int row = (q & 3) + 8 * (q >> 2) + 4 * h + (odd ? 1 : 0);
-            if (!FULL) { const int lim = (int)((int64_t)M - 1 - m0u - 32 * k); row = row < lim ? row : (lim > 0 ? lim : 0); }
-            rr[k][j][q >> 1] = *reinterpret_cast<const uint32_t*>(rb + row * ldres);
+            if (!FULL) {                                             // the partial unit: absolute row, clamped to the last row of the tensor
+              const int64_t ra = m0u + 32 * k + row;
+              rr[k][j][q >> 1] = *reinterpret_cast<const uint32_t*>(rb + (ra < M ? ra : (int64_t)M - 1) * ldres);
+            } else {
+              rr[k][j][q >> 1] = *reinterpret_cast<const uint32_t*>(rb + row * ldres);
+            }
           }
         }
     }
