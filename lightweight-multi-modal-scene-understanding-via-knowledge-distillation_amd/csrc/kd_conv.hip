@@ -4,6 +4,7 @@
 //   depthwise : camera_encoder.py:30-35, fusion_module.py:25-27,78   (deferred BN+act on load,
 //               BN stats in the epilogue); backward = transposed stencil + per-channel weight sums.
 #include "kd_common.h"
+#include <type_traits>
 
 #include <atomic>
 #include <cstdlib>
@@ -780,23 +781,40 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_s1_kernel(DwBwdArgs a, int nr
       xrl[slot][lc][tx] = xr;
     }
   };
-  for (int64_t it = srow; it < items; it += nrow_slab) {
-    const int strip = (int)(it % nstrip), sg = (int)((it / nstrip) % nseg), b = (int)(it / ((int64_t)nstrip * nseg));
-    const int w0 = strip * DT_COLS, h0 = sg * DW_SEG, h1 = h0 + DW_SEG < a.H ? h0 + DW_SEG : a.H;
-    RawDy pd, pd2;
-    RawX px;
+  RawDy pd, pd2;
+  RawX px;
+  auto item_coords = [&](int64_t t, int& b, int& w0, int& h0) {
+    const int strip = (int)(t % nstrip), sg = (int)((t / nstrip) % nseg);
+    b = (int)(t / ((int64_t)nstrip * nseg));
+    w0 = strip * DT_COLS; h0 = sg * DW_SEG;
+  };
+  if (srow < items) {
+    int b, w0, h0;
+    item_coords(srow, b, w0, h0);
     fetch_dy(b, h0 - 1, w0, pd);
     fetch_dy(b, h0, w0, pd2);
+  }
+  for (int64_t it = srow; it < items; it += nrow_slab) {
+    int b, w0, h0;
+    item_coords(it, b, w0, h0);
+    const int h1 = h0 + DW_SEG < a.H ? h0 + DW_SEG : a.H;
+    int bn, w0n, h0n;                                                 // the workgroup's next item (this one again when there is none)
+    item_coords(it + nrow_slab < items ? it + nrow_slab : it, bn, w0n, h0n);
     __syncthreads();                                                  // the previous item's readers are done with the rings
     commit_dy(pd, (h0 + 3) & 3);
     commit_dy(pd2, h0 & 3);
     fetch_dy(b, h0 + 1, w0, pd);
     fetch_x(b, h0, w0, px);
-    for (int hi = h0; hi < h1; ++hi) {
+    auto row = [&](int hi, auto last_tag) __attribute__((always_inline)) {
       commit_dy(pd, (hi + 1) & 3);
       commit_x(px, hi & 1);
-      fetch_dy(b, hi + 2, w0, pd);                                    // in flight during this row's arithmetic
-      fetch_x(b, hi + 1, w0, px);
+      if constexpr (!decltype(last_tag)::value) {
+        fetch_dy(b, hi + 2, w0, pd);                                  // in flight during this row's arithmetic
+        fetch_x(b, hi + 1, w0, px);
+      } else {                                                        // last row of the item: the NEXT item's first two dy rows instead of
+        fetch_dy(bn, h0n - 1, w0n, pd);                               // rows nobody uses -- the next item does not start cold
+        fetch_dy(bn, h0n, w0n, pd2);
+      }
       __syncthreads();                                                // ring depth 4 / 2: one barrier per row is enough
       const int lc = ty + 1, wi = w0 + ty;
       const float4 (*r0)[DT_CQ] = dyl[(hi + 3) & 3], (*r1)[DT_CQ] = dyl[hi & 3], (*r2)[DT_CQ] = dyl[(hi + 1) & 3];
@@ -830,7 +848,9 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_s1_kernel(DwBwdArgs a, int nr
         float* gp = a.gx + (((int64_t)b * a.H + hi) * a.W + wi) * a.C + c0;
         if (a.nt) kd_st4_nt(gp, acc); else kd_st4(gp, acc);
       }
-    }
+    };
+    for (int hi = h0; hi < h1 - 1; ++hi) row(hi, std::false_type{});
+    row(h1 - 1, std::true_type{});
   }
   // ---- per-workgroup partials: slab row `srow`, this chunk's channels (every (row, chunk) pair is written by exactly one
   // workgroup, zeros included, so the fixed-order slab reductions need no initialisation) ------------------------------------
