@@ -37,6 +37,11 @@
 
 int kd_gemm_split_mode();     // kd_gemm.hip: 1 = bf16x6 split products (default), 0 = exact-fp32 MFMA
 
+// Round 4, measured and not kept: the matrix wave that holds a 32 x 32 block of (dy . W2) finishing G1 itself (mask from the vector
+// waves' LDS copy of Y1, BatchNorm sums, sixteen dword stores from the accumulators; no stage tile, no vector-wave epilogue): the L2
+// kernel went from 8.69-8.75 to 9.37-9.47 ms in the step on the same box (tools/r4_ab_lb.sh) -- the sixteen LDS reads, selects and
+// stores sit in the matrix waves' issue stream between two chunks' MFMAs, and those waves are not as idle as the vector waves are busy.
+//
 // Dev build only (-DKD_LB_DBG): per-phase s_memtime totals over all waves of a role, read back through kd_lb_dbg_read
 // (tools/bench_lidar_bwd.py): [0..3] role B: dy conversion + LDS stores | load issue | wgrad k-loop | barrier wait;
 // [4..7] role A: dgrad k-loop | epilogue | a1 conversion + load issue | barrier wait; [8] iterations (role A waves)
