@@ -402,8 +402,9 @@ __global__ __launch_bounds__(256) void dw_fwd_sw_kernel(DwArgs a) {
 // segment is SEG + 2 row arrivals, the raw row two arrivals ahead is always in flight (during the last two arrivals of a segment: rows
 // 0 and 1 of the thread's next segment), and the arrival loop is fully unrolled: no control flow between the loads, exact vmcnt waits,
 // the window rotates by renaming.  Same fma order per output as dw_fwd_sw_kernel<1>: the same bits.  Ho must be a multiple of SEG.
-template <int SEG>
-__global__ __launch_bounds__(256) void dw_fwd_pipe_s1_kernel(DwArgs a) {
+template <int STRIDE, int SEG>
+__global__ __launch_bounds__(256) void dw_fwd_pipe_kernel(DwArgs a) {
+  constexpr int NA = STRIDE * SEG + (STRIDE == 1 ? 2 : 1);     // row arrivals of a segment: input rows STRIDE * h0 - 1 ... STRIDE * (h0 + SEG - 1) + 1
   __shared__ float red[2 * 256 * 4];
   const int tid = threadIdx.x;
   const int gidx = tid % a.groups, slot = tid / a.groups;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256) void dw_fwd_pipe_s1_kernel(DwArgs a) {
     };
     int b, h0, wo;
     coords(it, b, h0, wo);
-    DwRow qa = issue(b, h0 - 1, wo), qb = issue(b, h0, wo);
+    DwRow qa = issue(b, STRIDE * h0 - 1, wo * STRIDE), qb = issue(b, STRIDE * h0, wo * STRIDE);
     DwRow r0, r1, r2;
     r1.l = r1.c = r1.r = kd_zero4();
     r2.l = r2.c = r2.r = kd_zero4();
@@ -452,19 +453,19 @@ __global__ __launch_bounds__(256) void dw_fwd_pipe_s1_kernel(DwArgs a) {
       int bn, h0n, won;
       coords(more ? itn : it, bn, h0n, won);
 #pragma unroll
-      for (int k = 0; k < SEG + 2; ++k) {                      // arrival k is input row h0 - 1 + k
+      for (int k = 0; k < NA; ++k) {                           // arrival k is input row STRIDE * h0 - 1 + k
         const DwRow c = qa;
         qa = qb;
-        if (k + 2 < SEG + 2) qb = issue(b, h0 + 1 + k, wo);
-        else qb = issue(bn, h0n - 1 + (k - SEG), won);                                       // rows 0, 1 of the next segment
+        if (k + 2 < NA) qb = issue(b, STRIDE * h0 + 1 + k, wo * STRIDE);
+        else qb = issue(bn, STRIDE * h0n - 1 + (k + 2 - NA), won * STRIDE);                  // rows 0, 1 of the next segment
         r0 = r1; r1 = r2;
-        r2 = dw_finish_row(c, deferred, sc, sh, a.act, h0 - 1 + k, wo, a.H, a.W);
-        if (k >= 2) {
+        r2 = dw_finish_row(c, deferred, sc, sh, a.act, STRIDE * h0 - 1 + k, wo * STRIDE, a.H, a.W);
+        if (k >= 2 && (STRIDE == 1 || k % 2 == 0)) {           // stride 2: output row h0 + k / 2 - 1 is complete with its third row
           float4 acc = kd_zero4();
           dw_fma_row(acc, r0, wreg, 0);
           dw_fma_row(acc, r1, wreg, 1);
           dw_fma_row(acc, r2, wreg, 2);
-          float* dst = a.y + (((int64_t)b * a.Ho + (h0 + k - 2)) * a.Wo + wo) * a.C + c0;
+          float* dst = a.y + (((int64_t)b * a.Ho + (STRIDE == 1 ? h0 + k - 2 : h0 + k / 2 - 1)) * a.Wo + wo) * a.C + c0;
           if (a.nt) kd_st4_nt(dst, acc); else kd_st4(dst, acc);
           s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
           s2.x = fmaf(acc.x, acc.x, s2.x); s2.y = fmaf(acc.y, acc.y, s2.y);
@@ -1275,10 +1276,11 @@ int kd_dwconv3x3_fwd(const float* x, const float* sc, const float* sh, int act, 
   const DwLayout l = dw_layout((int64_t)B * Ho * Wo, C);
   DwArgs a{x, sc, sh, act, w, y, partial, B, H, W, C, Ho, Wo, stride, l.groups, l.slots, l.nchunk,
            kd_nt_store((size_t)B * Ho * Wo * C * sizeof(float))};
-  static const int pipe = [] { const char* e = getenv("KD_DW_FWD_PIPE"); return e ? atoi(e) : 1; }();
+  static const int pipe = [] { const char* e = getenv("KD_DW_FWD_PIPE"); return e ? atoi(e) : 3; }();     // bit 0: stride 1, bit 1: stride 2
   const bool small = (int64_t)B * H * W * C < ((int64_t)1 << 31);      // the pipelined kernel addresses x by 32-bit element offsets
-  if (stride == 1 && pipe && small && Ho % 16 == 0) hipLaunchKernelGGL(dw_fwd_pipe_s1_kernel<16>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
-  else if (stride == 1 && pipe && small && Ho % 8 == 0) hipLaunchKernelGGL(dw_fwd_pipe_s1_kernel<8>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (stride == 1 && (pipe & 1) && small && Ho % 16 == 0) hipLaunchKernelGGL((dw_fwd_pipe_kernel<1, 16>), dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (stride == 1 && (pipe & 1) && small && Ho % 8 == 0) hipLaunchKernelGGL((dw_fwd_pipe_kernel<1, 8>), dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (stride == 2 && (pipe & 2) && small && Ho % 8 == 0) hipLaunchKernelGGL((dw_fwd_pipe_kernel<2, 8>), dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   else if (stride == 1) hipLaunchKernelGGL(dw_fwd_sw_kernel<1>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(dw_fwd_sw_kernel<2>, dim3(l.grid), dim3(256), 0, (hipStream_t)stream, a);
   return kd_check_launch("kd_dwconv3x3_fwd");
